@@ -1,0 +1,149 @@
+/* sd_hip.h -- C ABI of libsd_hip.so: the gfx950 (MI355X / CDNA4) kernels and step runner of the
+ * Stage-2 distillation hot path of indiejoseph/speech-distill.
+ *
+ * The reference is pure Python and binds nothing native for this path; what it CALLS there are
+ * third-party CUDA kernels (flash_attn, cuBLAS, ATen).  Each entry point below cites the reference
+ * (or third-party HF) code whose arithmetic it replaces.  "HF:" = transformers/models/qwen3/
+ * modeling_qwen3.py, the decoder the reference instantiates at train.py:155-178.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host; bf16 tensors are row-major,
+ *     16-byte aligned, leading dimensions are in ELEMENTS and multiples of 8;
+ *   - `stream` is a hipStream_t (torch's current stream); launchers never allocate, never
+ *     synchronise and keep no global state; scratch comes from the caller (see *_workspace_bytes);
+ *   - return value: SD_OK (0), a negative SD_ERR_* code, or a positive hipError_t from the launch.
+ */
+#pragma once
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SD_OK 0
+#define SD_ERR_SHAPE (-1)
+#define SD_ERR_ALIGN (-2)
+#define SD_ERR_UNSUPPORTED (-3)
+#define SD_ERR_NO_TEACHER (-4) /* distillation_loss.py:120 ValueError("Either teacher_logits or top_k must be provided") */
+#define SD_ERR_WORKSPACE (-5)
+
+#define SD_DTYPE_BF16 0
+#define SD_DTYPE_F32 1
+
+int sd_abi_version(void);
+
+/* ---- GEMM: every nn.Linear of the decoder and its backward (HF:81-83, 252-254, 279, 441).
+ * C[M,N] = op(A) op(B) (+ R).  trans_a=0: A is [M][K]; 1: A is stored [K][M].  trans_b=0: B is [N][K]
+ * (torch weight layout); 1: B is stored [K][N].  R (nullable, may alias C) is added in fp32. */
+int sd_gemm_bf16(const void* A, const void* B, void* C, const void* R, int M, int N, int K, int64_t lda,
+                 int64_t ldb, int64_t ldc, int64_t ldr, int trans_a, int trans_b, void* stream);
+
+/* ---- RMSNorm (HF:59-64).  rstd (fp32 [M], nullable in fwd) is saved for backward. */
+int sd_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int M, int H, float eps, void* stream);
+int64_t sd_rmsnorm_bwd_workspace_bytes(int M, int H);
+/* dx = d(norm)/dx . dy (+ dres, nullable: the residual-stream gradient); dw (+)= sum_rows dy * xhat */
+int sd_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, const void* dres, void* dx,
+                   void* dw, int accumulate_dw, void* workspace, int M, int H, void* stream);
+
+/* ---- per-head q/k RMSNorm (head_dim 128) then rotate-half RoPE (HF:252-257, 121-170).
+ * qkv [M,(Hq+2Hkv)*128] -> qk_out [M,(Hq+Hkv)*128]; cos/sin tables bf16 [T,128]; token m has position m % T. */
+int sd_qknorm_rope_fwd(const void* qkv, const void* q_gain, const void* k_gain, const void* cos_tab,
+                       const void* sin_tab, void* qk_out, int M, int T, int Hq, int Hkv, float eps, void* stream);
+int64_t sd_qknorm_rope_bwd_workspace_bytes(int M, int Hq, int Hkv);
+int sd_qknorm_rope_bwd(const void* dqk, const void* qkv, const void* q_gain, const void* k_gain, const void* cos_tab,
+                       const void* sin_tab, void* dqkv, void* dq_gain, void* dk_gain, int accumulate_dw, void* workspace,
+                       int M, int T, int Hq, int Hkv, float eps, void* stream);
+
+/* ---- SwiGLU (HF:81-83): gate_up [M,2I] (gate | up) -> act [M,I] = silu(gate)*up */
+int sd_swiglu_fwd(const void* gate_up, void* act, int M, int I, void* stream);
+int sd_swiglu_bwd(const void* dact, const void* gate_up, void* dgate_up, int M, int I, void* stream);
+
+/* ---- embedding (HF:381) and its deterministic scatter-add backward (dE += rows of dx) */
+int sd_embedding_fwd(const int64_t* ids, const void* E, void* x, int M, int H, int V, void* stream);
+int sd_embedding_bwd(const int64_t* ids, const void* dx, void* dE, int M, int H, int V, void* stream);
+
+/* ---- causal GQA flash attention, head_dim 128 (flash_attn via train.py:160,177; maths HF:185-207).
+ * q [B*T, ldq] head hq at column hq*128; k, v likewise per kv head; o [B*T, ldo]; lse fp32 [B,Hq,T].
+ * kv_len (int32 [B], nullable): keys >= kv_len[b] are masked (right padding). */
+int sd_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const int32_t* kv_len, int64_t ldq,
+                int64_t ldk, int64_t ldv, int64_t ldo, int B, int T, int Hq, int Hkv, int head_dim, float scale,
+                void* stream);
+/* delta: fp32 [B,Hq,T] scratch (rowsum(dO*O)) */
+int sd_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse,
+                float* delta, void* dq, void* dk, void* dv, const int32_t* kv_len, int64_t ldq, int64_t ldk, int64_t ldv,
+                int64_t ldo, int64_t lddq, int64_t lddk, int64_t lddv, int B, int T, int Hq, int Hkv, int head_dim,
+                float scale, void* stream);
+
+/* ---- teacher log-softmax + top-K (train.py:80-91; extract_teacher_logits.py:114-129).
+ * logits [rows, row_stride], first V columns used -> top_v fp16 [rows,K], top_i int32 [rows,K] sorted
+ * descending, ties to the lowest index; lse_out fp32 [rows] nullable. */
+int sd_logsoftmax_topk(const void* logits, void* top_v, void* top_i, float* lse_out, int rows, int64_t row_stride,
+                       int V, int K, int dtype, void* stream);
+
+/* ---- DistillationLoss.forward / backward (distillation_loss.py:14-128).
+ * student_logits [B,T,V] (bf16 or fp32 per `dtype`); exactly one of teacher_logits [B,T,V] (dense) or
+ * (top_k_v fp16, top_k_i int32) [B,T,K] (sparse); labels int64 [B,T]; speech_mask uint8 [B,T] nullable.
+ * loss_out fp32[8] = {total, task, distill, teacher, N_valid, n_hits, 0, 0}; row_stats: scratch of
+ * sd_kdloss_stats_bytes(B,T) kept from fwd to bwd.  grad_total: fp32[1] upstream gradient (nullable = 1).
+ * grad_logits may alias student_logits. */
+int64_t sd_kdloss_stats_bytes(int B, int T);
+int sd_kdloss_fwd(const void* student_logits, const void* teacher_logits, const void* top_k_v, const void* top_k_i,
+                  const int64_t* labels, const uint8_t* speech_mask, void* row_stats, float* loss_out, int B, int T, int V,
+                  int K, float temperature, float alpha, int dtype, void* stream);
+int sd_kdloss_bwd(const void* student_logits, const void* teacher_logits, const void* top_k_v, const void* top_k_i,
+                  const int64_t* labels, const void* row_stats, const float* loss_out, const float* grad_total,
+                  void* grad_logits, int B, int T, int V, int K, float temperature, float alpha, int dtype, void* stream);
+
+/* ---- fused AdamW on bf16 params with bf16 state (HF Trainer default optimizer on the bf16 student,
+ * train.py:174,331-354; quirk Q5) and the global grad-norm / clip (HF trainer max_grad_norm). */
+int sd_sumsq_bf16(const void* x, int64_t n, float* out_accum, void* stream);
+int sd_adamw_bf16(void* param, const void* grad, void* exp_avg, void* exp_avg_sq, int64_t n, float lr, float beta1,
+                  float beta2, float eps, float weight_decay, int step, const float* grad_sumsq, float max_grad_norm,
+                  void* stream);
+
+/* ---- whole-decoder runner: Qwen3ForCausalLM forward (HF:381-441) / backward, one C call each.
+ * Weight layout: q|k|v projections fused row-wise into wqkv [(Hq+2Hkv)*128, h]; gate|up into wgu [2I, h]. */
+typedef struct {
+  int32_t vocab, hidden, inter, layers, n_q, n_kv, head_dim, tied;
+  float eps;
+  int32_t pad_;
+} sd_qwen3_dims;
+
+typedef struct {
+  void *wqkv, *wo, *wgu, *wdown, *q_gain, *k_gain, *ln1, *ln2;
+} sd_qwen3_layer;
+
+typedef struct {
+  void* embed;      /* [V,h] */
+  void* lm_head;    /* [V,h]; == embed when tied */
+  void* final_norm; /* [h] */
+  const sd_qwen3_layer* layers_host; /* HOST array of `layers` entries holding DEVICE pointers */
+} sd_qwen3_params;
+
+/* bytes of activation storage for `sd_qwen3_forward`; save_for_backward=0: inference (teacher) */
+int64_t sd_qwen3_acts_bytes(const sd_qwen3_dims* d, int B, int T, int save_for_backward);
+int64_t sd_qwen3_bwd_scratch_bytes(const sd_qwen3_dims* d, int B, int T);
+
+/* ids int64 [B,T]; kv_len int32 [B] nullable; cos/sin bf16 [T,128]; acts: caller buffer of
+ * sd_qwen3_acts_bytes; logits bf16 [B*T, V] out (nullable: stop after the final norm);
+ * hidden_out bf16 [B*T,h] nullable */
+int sd_qwen3_forward(const sd_qwen3_dims* d, const sd_qwen3_params* p, const int64_t* ids, const int32_t* kv_len,
+                     const void* cos_tab, const void* sin_tab, void* acts, int64_t acts_bytes, void* logits, int B, int T,
+                     int save_for_backward, void* stream);
+/* g: same structure as p but holding gradient buffers (bf16, same shapes); dlogits bf16 [B*T,V];
+ * accumulate: 0 overwrite grads, 1 add to them (gradient accumulation).
+ * on_grads_ready (nullable) is called ON THE HOST, from inside this call, each time the kernels that
+ * finish one group of gradients have been enqueued on `stream`: stage = SD_STAGE_HEAD (lm_head dW
+ * + final norm, before any layer), layer index L-1..0 (that layer's 8 tensors), SD_STAGE_EMBED (the
+ * embedding scatter-add, last).  A data-parallel caller records an event there and starts that
+ * bucket's RCCL all-reduce on a second stream, overlapping it with the rest of backward. */
+#define SD_STAGE_HEAD (-1)
+#define SD_STAGE_EMBED (-2)
+typedef void (*sd_stage_cb)(int stage, void* user);
+int sd_qwen3_backward(const sd_qwen3_dims* d, const sd_qwen3_params* p, const sd_qwen3_params* g, const int64_t* ids,
+                      const int32_t* kv_len, const void* cos_tab, const void* sin_tab, void* acts, int64_t acts_bytes,
+                      void* dlogits, void* scratch, int64_t scratch_bytes, int B, int T, int accumulate,
+                      sd_stage_cb on_grads_ready, void* cb_user, void* stream);
+
+#ifdef __cplusplus
+}
+#endif

@@ -1,0 +1,97 @@
+"""ctypes binding of libsd_hip.so (the C ABI declared in include/sd_hip.h).
+
+The library is built in-tree by ``make -C speech_distill_amd/csrc`` (or ``__graft_entry__.build()``).
+Loading fails loudly: there is no Python/CPU fallback behind any of these symbols.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+ERRORS = {-1: "SD_ERR_SHAPE", -2: "SD_ERR_ALIGN", -3: "SD_ERR_UNSUPPORTED", -4: "SD_ERR_NO_TEACHER",
+          -5: "SD_ERR_WORKSPACE"}
+
+
+class SdHipError(RuntimeError):
+    pass
+
+
+def lib_path() -> str:
+    return os.path.join(_HERE, "libsd_hip.so")
+
+
+class Dims(C.Structure):
+    _fields_ = [("vocab", C.c_int32), ("hidden", C.c_int32), ("inter", C.c_int32), ("layers", C.c_int32),
+                ("n_q", C.c_int32), ("n_kv", C.c_int32), ("head_dim", C.c_int32), ("tied", C.c_int32),
+                ("eps", C.c_float), ("pad_", C.c_int32)]
+
+
+class Layer(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("wqkv", "wo", "wgu", "wdown", "q_gain", "k_gain", "ln1", "ln2")]
+
+
+class Params(C.Structure):
+    _fields_ = [("embed", C.c_void_p), ("lm_head", C.c_void_p), ("final_norm", C.c_void_p),
+                ("layers_host", C.POINTER(Layer))]
+
+
+STAGE_CB = C.CFUNCTYPE(None, C.c_int, C.c_void_p)
+
+_vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
+# name -> (restype, argtypes); must list every symbol include/sd_hip.h declares (tests check this)
+PROTOTYPES = {
+    "sd_abi_version": (_i, []),
+    "sd_gemm_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _i64, _i64, _i, _i, _vp]),
+    "sd_rmsnorm_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
+    "sd_rmsnorm_bwd_workspace_bytes": (_i64, [_i, _i]),
+    "sd_rmsnorm_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _vp]),
+    "sd_qknorm_rope_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
+    "sd_qknorm_rope_bwd_workspace_bytes": (_i64, [_i, _i, _i]),
+    "sd_qknorm_rope_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _f, _vp]),
+    "sd_swiglu_fwd": (_i, [_vp, _vp, _i, _i, _vp]),
+    "sd_swiglu_bwd": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
+    "sd_embedding_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    "sd_embedding_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    "sd_attn_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _i, _f, _vp]),
+    "sd_attn_bwd": (_i, [_vp] * 11 + [_i64] * 7 + [_i, _i, _i, _i, _i, _f, _vp]),
+    "sd_logsoftmax_topk": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _i, _i, _vp]),
+    "sd_kdloss_stats_bytes": (_i64, [_i, _i]),
+    "sd_kdloss_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _i, _vp]),
+    "sd_kdloss_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _i, _vp]),
+    "sd_sumsq_bf16": (_i, [_vp, _i64, _vp, _vp]),
+    "sd_adamw_bf16": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _vp, _f, _vp]),
+    "sd_qwen3_acts_bytes": (_i64, [C.POINTER(Dims), _i, _i, _i]),
+    "sd_qwen3_bwd_scratch_bytes": (_i64, [C.POINTER(Dims), _i, _i]),
+    "sd_qwen3_forward": (_i, [C.POINTER(Dims), C.POINTER(Params), _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i, _i, _i, _vp]),
+    "sd_qwen3_backward": (_i, [C.POINTER(Dims), C.POINTER(Params), C.POINTER(Params), _vp, _vp, _vp, _vp, _vp, _i64,
+                               _vp, _vp, _i64, _i, _i, _i, STAGE_CB, _vp, _vp]),
+}
+
+
+def load_lib():
+    """Load libsd_hip.so once; raise SdHipError (never fall back) when it is absent."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise SdHipError(
+            f"{path} not found: build it with `make -C speech_distill_amd/csrc` (hipcc --offload-arch=gfx950). "
+            "speech_distill_amd has no CPU fallback.")
+    lib = C.CDLL(path)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    _LIB = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc == 0:
+        return
+    if rc == -4:
+        raise ValueError("Either teacher_logits or top_k must be provided")  # distillation_loss.py:120
+    raise SdHipError(f"{what} failed: {ERRORS.get(rc, 'hipError_t ' + str(rc))}")

@@ -1,0 +1,467 @@
+// Causal GQA flash attention (head_dim 128) forward + backward for gfx950, bf16 in/out, fp32 softmax.
+//
+// Replaces the flash_attn kernels the reference selects with attn_implementation="flash_attention_2"
+// (train.py:160,177); the maths is HF eager_attention_forward (modeling_qwen3.py:185-207):
+//     softmax(Q K^T d^-1/2 + causal/key-padding mask, fp32) V,  kv head j serves q heads jG..jG+G-1.
+//
+// All three kernels use v_mfma_f32_32x32x16_bf16 and ONE LDS image for every [rows][128] bf16 tile:
+//     off(row, chunk16B) = 256*row + 16*(chunk ^ (((row&3)<<2) | ((row>>2)&3)))
+// which is bank-conflict-free both for row reads (ds_read_b128, operand whose k index is d) and for
+// transposed reads (ds_read_b64_tr_b16, operand whose k index is the row).  Tiles arrive by 16-byte
+// LDS-DMA with the swizzle applied on the per-lane source address, double buffered.
+//
+// forward / dQ kernels: S^T = K Q^T, so a lane owns ONE query row (column l&31 of the 32x32 tile) and
+//   the online softmax, the LSE / delta terms and the rescale are lane-local; P^T (dS^T) accumulator
+//   registers feed the next MFMA as its B operand with no lane movement: O^T = V^T P^T, dQ^T = K^T dS^T.
+// dK/dV kernel: S = Q K^T with the key on the lane; a wave owns 32 keys and keeps dK^T, dV^T in
+//   registers over all query tiles and all G query heads of its kv head (no atomics, deterministic):
+//   dV^T = dO^T P, dK^T = Q^T dS.
+#include "sd_common.cuh"
+#include "../../include/sd_hip.h"
+
+namespace {
+
+constexpr int D = 128;
+constexpr int TILE = 64 * D * 2;  // one 64-row tile: 16 KiB
+constexpr float NEG = -1.0e30f;
+constexpr float LOG2E = 1.4426950408889634f;
+
+SD_DEV int f_swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+
+// Stage rows [row0, row0+64) of a [*, 128]-column slice (row stride ld) into a 16 KiB LDS tile.
+// Rows are clamped to [0, row_max] (finite data; masked later).
+SD_DEV void stage64(const bf16* __restrict__ g, long ld, int row0, int row_max, char* lds, int w, int lane) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int p = (w * 4 + i) * 64 + lane;
+    const int row = p >> 4, s = p & 15;
+    const int ch = s ^ f_swz(row);
+    int gr = row0 + row;
+    gr = gr > row_max ? row_max : gr;
+    glds16(g + (long)gr * ld + ch * 8, lds + (w * 4 + i) * 1024);
+  }
+}
+
+// operand whose k index is d: lane (r = l&31, h = l>>5) holds tile[row0 + r][16*st + 8h .. +7]
+SD_DEV bf16x8 row_frag(const char* lds, int row0, int st, int lane) {
+  const int row = row0 + (lane & 31);
+  const int ch = 2 * st + (lane >> 5);
+  return *(const bf16x8*)(lds + row * 256 + ((ch ^ f_swz(row)) << 4));
+}
+
+// operand whose k index is the tile row: lane (r = l&31 -> column db*32 + r, h = l>>5) holds
+// tile[rb + 8(j>>2) + 4h + (j&3)][db*32 + r], j = 0..7  (rb = first row of this 16-row k-step).
+// This is exactly the k order of accumulator registers 8s..8s+7 used as the other operand.
+SD_DEV bf16x8 tr_frag(const char* lds, int rb, int db, int lane) {
+  const int gi = lane >> 4, i = lane & 15, q4 = i >> 2, pp = i & 3;
+  const int rA = rb + 4 * (gi >> 1) + q4, rB = rA + 8;
+  const int ch = db * 4 + (gi & 1) * 2 + (pp >> 1);
+  const int sub = 8 * (pp & 1);
+  bf16x4 lo = lds_tr16(lds + rA * 256 + ((ch ^ f_swz(rA)) << 4) + sub);
+  bf16x4 hi = lds_tr16(lds + rB * 256 + ((ch ^ f_swz(rB)) << 4) + sub);
+  return cat8(lo, hi);
+}
+
+SD_DEV bf16x8 acc_frag(const f32x16& p, int s) {
+  bf16x8 r;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) r[j] = (bf16)p[8 * s + j];
+  return r;
+}
+
+// row index (within a 32x32 accumulator tile) of register `reg` for lane half h
+SD_DEV int acc_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
+
+// ------------------------------------------------------------------------------------------ forward
+// grid (ceil(T/128), Hq, B), 256 threads: wave w owns query rows q0 + 32w .. +31.
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ Kp,
+                                                       const bf16* __restrict__ Vp, bf16* __restrict__ O,
+                                                       float* __restrict__ LSE, const int* __restrict__ kv_len, long ldq,
+                                                       long ldk, long ldv, long ldo, int T, int Hq, int Hkv,
+                                                       float scale) {
+  __shared__ __attribute__((aligned(16))) char smem[4 * TILE];  // 2 stages x (K,V)
+  const int lane = lane_id(), w = wave_id_uniform();
+  const int qt = gridDim.x - 1 - blockIdx.x;  // heaviest (latest) query tiles first
+  const int hq = blockIdx.y, b = blockIdx.z;
+  const int hkv = hq / (Hq / Hkv);
+  const int q0 = qt * 128, q0w = q0 + 32 * w;
+  const int r = lane & 31, h = lane >> 5;
+  const int klen = kv_len ? max(1, min(kv_len[b], T)) : T;
+  const long tok0 = (long)b * T;
+  const bf16* qb = Q + tok0 * ldq + hq * D;
+  const bf16* kb = Kp + tok0 * ldk + hkv * D;
+  const bf16* vb = Vp + tok0 * ldv + hkv * D;
+
+  const int q = q0w + r;  // this lane's query row
+  const int qc = q < T ? q : T - 1;
+  bf16x8 qf[8];
+#pragma unroll
+  for (int st = 0; st < 8; ++st) qf[st] = *(const bf16x8*)(qb + (long)qc * ldq + 16 * st + 8 * h);
+  const int lim = min(q, klen - 1);  // keys > lim are masked for this row
+
+  f32x16 o[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[db][e] = 0.f;
+  float m = NEG, l = 0.f;
+  const float c = scale * LOG2E;
+
+  const int kv_hi = min(q0 + 128, T);
+  const int nkv = (kv_hi + 63) / 64;
+  stage64(kb, ldk, 0, T - 1, smem, w, lane);
+  stage64(vb, ldv, 0, T - 1, smem + TILE, w, lane);
+  __syncthreads();
+  for (int t = 0; t < nkv; ++t) {
+    const char* ks = smem + (t & 1) * 2 * TILE;
+    const char* vs = ks + TILE;
+    if (t + 1 < nkv) {
+      char* nx = smem + ((t + 1) & 1) * 2 * TILE;
+      stage64(kb, ldk, (t + 1) * 64, T - 1, nx, w, lane);
+      stage64(vb, ldv, (t + 1) * 64, T - 1, nx + TILE, w, lane);
+    }
+    const int kv0 = t * 64;
+    if (kv0 <= q0w + 31) {  // wave-uniform: some key of this tile is visible to some row of this wave
+      f32x16 s[2];
+#pragma unroll
+      for (int kb2 = 0; kb2 < 2; ++kb2) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s[kb2][e] = 0.f;
+#pragma unroll
+        for (int st = 0; st < 8; ++st) s[kb2] = mfma32(row_frag(ks, kb2 * 32, st, lane), qf[st], s[kb2]);
+      }
+      float mx = NEG;
+#pragma unroll
+      for (int kb2 = 0; kb2 < 2; ++kb2)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int key = kv0 + kb2 * 32 + acc_row(e, h);
+          const float v = key > lim ? NEG : s[kb2][e];
+          s[kb2][e] = v;
+          mx = fmaxf(mx, v);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float mn = fmaxf(m, mx);
+      const float alpha = exp2f((m - mn) * c);
+      m = mn;
+      float rs = 0.f;
+#pragma unroll
+      for (int kb2 = 0; kb2 < 2; ++kb2)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const float p = exp2f((s[kb2][e] - mn) * c);
+          s[kb2][e] = p;
+          rs += p;
+        }
+      l = l * alpha + rs;
+#pragma unroll
+      for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[db][e] *= alpha;
+#pragma unroll
+      for (int kb2 = 0; kb2 < 2; ++kb2)
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss) {
+          const bf16x8 pf = acc_frag(s[kb2], ss);
+#pragma unroll
+          for (int db = 0; db < 4; ++db) o[db] = mfma32(tr_frag(vs, kb2 * 32 + 16 * ss, db, lane), pf, o[db]);
+        }
+    }
+    __syncthreads();
+  }
+  l += __shfl_xor(l, 32, 64);
+  const float inv = 1.f / l;
+  if (q < T) {
+    bf16* orow = O + (tok0 + q) * ldo + hq * D;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        bf16x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (bf16)(o[db][4 * g4 + e] * inv);
+        *(bf16x4*)(orow + db * 32 + 8 * g4 + 4 * h) = v;
+      }
+    if (h == 0) LSE[((long)b * Hq + hq) * T + q] = m * scale + __logf(l);
+  }
+}
+
+// -------------------------------------------------------------------------- delta = rowsum(dO * O)
+__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16* __restrict__ dO, const bf16* __restrict__ O,
+                                                         float* __restrict__ delta, long ldo, int T, int Hq, long total) {
+  const int lane = lane_id();
+  const long idx = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);  // (token, head)
+  const int j = lane & 15;
+  const bool ok = idx < total;
+  const long id = ok ? idx : total - 1;
+  const long tok = id / Hq;
+  const int hh = (int)(id % Hq);
+  bf16x8 a = *(const bf16x8*)(dO + tok * ldo + hh * D + j * 8);
+  bf16x8 bb = *(const bf16x8*)(O + tok * ldo + hh * D + j * 8);
+  float s = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s += (float)a[e] * (float)bb[e];
+  s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64);
+  if (ok && j == 0) {
+    const long bidx = tok / T;
+    const int t = (int)(tok % T);
+    delta[(bidx * Hq + hh) * T + t] = s;
+  }
+}
+
+// ----------------------------------------------------------------------------------------------- dQ
+// Same decomposition as forward.  dQ^T[d][q] = scale * sum_key K^T[d][key] dS^T[key][q].
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ Kp,
+                                                          const bf16* __restrict__ Vp, const bf16* __restrict__ dO,
+                                                          const float* __restrict__ LSE, const float* __restrict__ delta,
+                                                          bf16* __restrict__ dQ, const int* __restrict__ kv_len, long ldq,
+                                                          long ldk, long ldv, long ldo, long lddq, int T, int Hq, int Hkv,
+                                                          float scale) {
+  __shared__ __attribute__((aligned(16))) char smem[4 * TILE];
+  const int lane = lane_id(), w = wave_id_uniform();
+  const int qt = gridDim.x - 1 - blockIdx.x;
+  const int hq = blockIdx.y, b = blockIdx.z;
+  const int hkv = hq / (Hq / Hkv);
+  const int q0 = qt * 128, q0w = q0 + 32 * w;
+  const int r = lane & 31, h = lane >> 5;
+  const int klen = kv_len ? max(1, min(kv_len[b], T)) : T;
+  const long tok0 = (long)b * T;
+  const bf16* qb = Q + tok0 * ldq + hq * D;
+  const bf16* kb = Kp + tok0 * ldk + hkv * D;
+  const bf16* vb = Vp + tok0 * ldv + hkv * D;
+  const bf16* dob = dO + tok0 * ldo + hq * D;
+  const int q = q0w + r;
+  const int qc = q < T ? q : T - 1;
+  bf16x8 qf[8], dof[8];
+#pragma unroll
+  for (int st = 0; st < 8; ++st) {
+    qf[st] = *(const bf16x8*)(qb + (long)qc * ldq + 16 * st + 8 * h);
+    dof[st] = *(const bf16x8*)(dob + (long)qc * ldo + 16 * st + 8 * h);
+  }
+  const int lim = min(q, klen - 1);
+  const float lse2 = LSE[((long)b * Hq + hq) * T + qc] * LOG2E;
+  const float dl = delta[((long)b * Hq + hq) * T + qc];
+  const float c = scale * LOG2E;
+  f32x16 acc[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[db][e] = 0.f;
+
+  const int kv_hi = min(q0 + 128, T);
+  const int nkv = (kv_hi + 63) / 64;
+  stage64(kb, ldk, 0, T - 1, smem, w, lane);
+  stage64(vb, ldv, 0, T - 1, smem + TILE, w, lane);
+  __syncthreads();
+  for (int t = 0; t < nkv; ++t) {
+    const char* ks = smem + (t & 1) * 2 * TILE;
+    const char* vs = ks + TILE;
+    if (t + 1 < nkv) {
+      char* nx = smem + ((t + 1) & 1) * 2 * TILE;
+      stage64(kb, ldk, (t + 1) * 64, T - 1, nx, w, lane);
+      stage64(vb, ldv, (t + 1) * 64, T - 1, nx + TILE, w, lane);
+    }
+    const int kv0 = t * 64;
+    if (kv0 <= q0w + 31) {
+#pragma unroll
+      for (int kb2 = 0; kb2 < 2; ++kb2) {
+        f32x16 s, dp;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
+#pragma unroll
+        for (int st = 0; st < 8; ++st) {
+          s = mfma32(row_frag(ks, kb2 * 32, st, lane), qf[st], s);     // S^T  = K Q^T
+          dp = mfma32(row_frag(vs, kb2 * 32, st, lane), dof[st], dp);  // dP^T = V dO^T
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int key = kv0 + kb2 * 32 + acc_row(e, h);
+          const float p = key > lim ? 0.f : exp2f(s[e] * c - lse2);
+          s[e] = p * (dp[e] - dl);  // dS^T (without the d^-1/2 factor)
+        }
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss) {
+          const bf16x8 df = acc_frag(s, ss);
+#pragma unroll
+          for (int db = 0; db < 4; ++db) acc[db] = mfma32(tr_frag(ks, kb2 * 32 + 16 * ss, db, lane), df, acc[db]);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (q < T) {
+    bf16* orow = dQ + (tok0 + q) * lddq + hq * D;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        bf16x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (bf16)(acc[db][4 * g4 + e] * scale);
+        *(bf16x4*)(orow + db * 32 + 8 * g4 + 4 * h) = v;
+      }
+  }
+}
+
+// -------------------------------------------------------------------------------------------- dK, dV
+// grid (ceil(T/128), Hkv, B): wave w owns keys k0 + 32w .. +31 of kv head hkv; loops over the G query
+// heads of the group and over 64-row query tiles at or below the diagonal.
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ Kp,
+                                                           const bf16* __restrict__ Vp, const bf16* __restrict__ dO,
+                                                           const float* __restrict__ LSE, const float* __restrict__ delta,
+                                                           bf16* __restrict__ dK, bf16* __restrict__ dV,
+                                                           const int* __restrict__ kv_len, long ldq, long ldk, long ldv,
+                                                           long ldo, long lddk, long lddv, int T, int Hq, int Hkv,
+                                                           float scale) {
+  __shared__ __attribute__((aligned(16))) char smem[4 * TILE];  // 2 stages x (Q, dO)
+  __shared__ __attribute__((aligned(16))) float stat[2][2][64];  // [stage][lse2|delta][q row]
+  const int lane = lane_id(), w = wave_id_uniform();
+  const int hkv = blockIdx.y, b = blockIdx.z;
+  const int G = Hq / Hkv;
+  const int k0 = blockIdx.x * 128, k0w = k0 + 32 * w;
+  const int r = lane & 31, h = lane >> 5;
+  const int klen = kv_len ? max(1, min(kv_len[b], T)) : T;
+  const long tok0 = (long)b * T;
+  const bf16* kb = Kp + tok0 * ldk + hkv * D;
+  const bf16* vb = Vp + tok0 * ldv + hkv * D;
+  const int key = k0w + r;  // this lane's key (column of S)
+  const int keyc = key < T ? key : T - 1;
+  bf16x8 kf[8], vf[8];
+#pragma unroll
+  for (int st = 0; st < 8; ++st) {
+    kf[st] = *(const bf16x8*)(kb + (long)keyc * ldk + 16 * st + 8 * h);
+    vf[st] = *(const bf16x8*)(vb + (long)keyc * ldv + 16 * st + 8 * h);
+  }
+  const bool key_ok = key < klen;  // padded / out-of-range keys receive no probability
+  const float c = scale * LOG2E;
+  f32x16 dk[4], dv[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { dk[db][e] = 0.f; dv[db][e] = 0.f; }
+
+  const int qt0 = k0 / 64;             // first 64-row query tile that can see a key of this block
+  const int nqt = (T + 63) / 64;
+  const int per_head = nqt - qt0;
+  const int nit = G * per_head;
+  auto stage_it = [&](int it, int buf) {
+    const int g = it / per_head, qt = qt0 + it % per_head;
+    const int hq = hkv * G + g;
+    char* dst = smem + buf * 2 * TILE;
+    stage64(Q + tok0 * ldq + hq * D, ldq, qt * 64, T - 1, dst, w, lane);
+    stage64(dO + tok0 * ldo + hq * D, ldo, qt * 64, T - 1, dst + TILE, w, lane);
+    if (threadIdx.x < 128) {
+      const int i = threadIdx.x & 63, which = threadIdx.x >> 6;
+      int qq = qt * 64 + i;
+      qq = qq < T ? qq : T - 1;
+      const long o = ((long)b * Hq + hq) * T + qq;
+      stat[buf][which][i] = which ? delta[o] : LSE[o] * LOG2E;
+    }
+  };
+  stage_it(0, 0);
+  __syncthreads();
+  for (int it = 0; it < nit; ++it) {
+    const int buf = it & 1;
+    const char* qs = smem + buf * 2 * TILE;
+    const char* dos = qs + TILE;
+    if (it + 1 < nit) stage_it(it + 1, buf ^ 1);
+    const int qbase = (qt0 + it % per_head) * 64;
+#pragma unroll
+    for (int qb2 = 0; qb2 < 2; ++qb2) {
+      const int qb0 = qbase + qb2 * 32;
+      if (qb0 + 31 < k0w) continue;  // wave-uniform: the whole 32-row block is above this wave's keys
+      f32x16 s, dp;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
+#pragma unroll
+      for (int st = 0; st < 8; ++st) {
+        s = mfma32(row_frag(qs, qb2 * 32, st, lane), kf[st], s);      // S  = Q K^T   (rows q, col key)
+        dp = mfma32(row_frag(dos, qb2 * 32, st, lane), vf[st], dp);   // dP = dO V^T
+      }
+      f32x16 ds;
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const f32x4 l2 = *(const f32x4*)&stat[buf][0][qb2 * 32 + 8 * g4 + 4 * h];
+        const f32x4 dl = *(const f32x4*)&stat[buf][1][qb2 * 32 + 8 * g4 + 4 * h];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int qq = qb0 + 8 * g4 + 4 * h + e;
+          const bool vis = key_ok && key <= qq && qq < T;
+          const float p = vis ? exp2f(s[4 * g4 + e] * c - l2[e]) : 0.f;
+          s[4 * g4 + e] = p;
+          ds[4 * g4 + e] = p * (dp[4 * g4 + e] - dl[e]);
+        }
+      }
+#pragma unroll
+      for (int ss = 0; ss < 2; ++ss) {
+        const bf16x8 pf = acc_frag(s, ss), df = acc_frag(ds, ss);
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+          dv[db] = mfma32(tr_frag(dos, qb2 * 32 + 16 * ss, db, lane), pf, dv[db]);  // dV^T += dO^T P
+          dk[db] = mfma32(tr_frag(qs, qb2 * 32 + 16 * ss, db, lane), df, dk[db]);   // dK^T += Q^T dS
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (key < T) {
+    bf16* kr = dK + (tok0 + key) * lddk + hkv * D;
+    bf16* vr = dV + (tok0 + key) * lddv + hkv * D;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        bf16x4 a, bb;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          a[e] = (bf16)(dk[db][4 * g4 + e] * scale);
+          bb[e] = (bf16)dv[db][4 * g4 + e];
+        }
+        *(bf16x4*)(kr + db * 32 + 8 * g4 + 4 * h) = a;
+        *(bf16x4*)(vr + db * 32 + 8 * g4 + 4 * h) = bb;
+      }
+  }
+}
+
+int check_common(int B, int T, int Hq, int Hkv, long ldq, long ldk, long ldv, long ldo) {
+  if (B <= 0 || T <= 0 || Hq <= 0 || Hkv <= 0 || (Hq % Hkv)) return SD_ERR_SHAPE;
+  if ((ldq | ldk | ldv | ldo) & 7) return SD_ERR_ALIGN;
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int sd_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const int32_t* kv_len,
+                           int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int B, int T, int Hq, int Hkv,
+                           int head_dim, float scale, void* stream) {
+  if (head_dim != D) return SD_ERR_UNSUPPORTED;
+  if (int e = check_common(B, T, Hq, Hkv, ldq, ldk, ldv, ldo)) return e;
+  if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) & 15) return SD_ERR_ALIGN;
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3((T + 127) / 128, Hq, B), dim3(256), 0, (hipStream_t)stream, (const bf16*)q,
+                     (const bf16*)k, (const bf16*)v, (bf16*)o, lse, kv_len, ldq, ldk, ldv, ldo, T, Hq, Hkv, scale);
+  SD_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int sd_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse,
+                           float* delta, void* dq, void* dk, void* dv, const int32_t* kv_len, int64_t ldq, int64_t ldk,
+                           int64_t ldv, int64_t ldo, int64_t lddq, int64_t lddk, int64_t lddv, int B, int T, int Hq,
+                           int Hkv, int head_dim, float scale, void* stream) {
+  if (head_dim != D) return SD_ERR_UNSUPPORTED;
+  if (int e = check_common(B, T, Hq, Hkv, ldq, ldk, ldv, ldo)) return e;
+  if ((lddq | lddk | lddv) & 7) return SD_ERR_ALIGN;
+  hipStream_t st = (hipStream_t)stream;
+  const long total = (long)B * T * Hq;
+  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, st, (const bf16*)d_o,
+                     (const bf16*)o, delta, ldo, T, Hq, total);
+  SD_CHECK_LAUNCH();
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((T + 127) / 128, Hkv, B), dim3(256), 0, st, (const bf16*)q, (const bf16*)k,
+                     (const bf16*)v, (const bf16*)d_o, lse, (const float*)delta, (bf16*)dk, (bf16*)dv, kv_len, ldq, ldk,
+                     ldv, ldo, lddk, lddv, T, Hq, Hkv, scale);
+  SD_CHECK_LAUNCH();
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((T + 127) / 128, Hq, B), dim3(256), 0, st, (const bf16*)q, (const bf16*)k,
+                     (const bf16*)v, (const bf16*)d_o, lse, (const float*)delta, (bf16*)dq, kv_len, ldq, ldk, ldv, ldo,
+                     lddq, T, Hq, Hkv, scale);
+  SD_CHECK_LAUNCH();
+  return 0;
+}

@@ -1,0 +1,185 @@
+// Host-side runner: one C call launches the whole Qwen3 decoder forward (student or frozen teacher)
+// or the whole student backward on a HIP stream, kernel after kernel, with every activation laid
+// out in one caller-provided HBM buffer (288 GB per MI355X: nothing is recomputed, nothing is
+// re-allocated).  Mirrors HF Qwen3ForCausalLM.forward (modeling_qwen3.py:381-441, layer 304-323)
+// as the reference calls it at train.py:54 (student, with grad) and train.py:60-69 (teacher, no grad).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/sd_hip.h"
+
+namespace {
+
+inline int64_t al(int64_t x) { return (x + 255) & ~(int64_t)255; }
+
+struct Sizes {
+  int M, h, I, QD, KD, QKV, QK, V, L, Hq, Hkv;
+  int64_t x, rstd, qkv, qk, ao, lse, gu, act;
+  Sizes(const sd_qwen3_dims* d, int B, int T) {
+    M = B * T; h = d->hidden; I = d->inter; Hq = d->n_q; Hkv = d->n_kv;
+    QD = Hq * d->head_dim; KD = Hkv * d->head_dim; QKV = QD + 2 * KD; QK = QD + KD; V = d->vocab; L = d->layers;
+    x = al((int64_t)M * h * 2); rstd = al((int64_t)M * 4); qkv = al((int64_t)M * QKV * 2); qk = al((int64_t)M * QK * 2);
+    ao = al((int64_t)M * QD * 2); lse = al((int64_t)B * Hq * T * 4); gu = al((int64_t)M * 2 * I * 2);
+    act = al((int64_t)M * I * 2);
+  }
+  int64_t per_layer() const { return 4 * x + 2 * rstd + qkv + qk + ao + lse + gu + act; }
+  int64_t tail() const { return 2 * x + rstd; }
+};
+
+struct LayerActs {
+  char *x_in, *rstd1, *xn1, *qkv, *qk, *ao, *lse, *x_mid, *rstd2, *xn2, *gu, *act;
+};
+
+LayerActs carve(const Sizes& s, char* p) {
+  LayerActs a;
+  a.x_in = p; p += s.x;
+  a.rstd1 = p; p += s.rstd;
+  a.xn1 = p; p += s.x;
+  a.qkv = p; p += s.qkv;
+  a.qk = p; p += s.qk;
+  a.ao = p; p += s.ao;
+  a.lse = p; p += s.lse;
+  a.x_mid = p; p += s.x;
+  a.rstd2 = p; p += s.rstd;
+  a.xn2 = p; p += s.x;
+  a.gu = p; p += s.gu;
+  a.act = p; p += s.act;
+  return a;
+}
+
+struct BwdScratch {
+  char *dx_a, *dx_b, *dxn, *dqkv, *dqk, *dao, *delta, *dgu, *dact, *ws_norm, *ws_qk;
+  int64_t total;
+  BwdScratch(const Sizes& s, char* p) {
+    char* p0 = p;
+    dx_a = p; p += s.x;
+    dx_b = p; p += s.x;
+    dxn = p; p += s.x;
+    dqkv = p; p += s.qkv;
+    dqk = p; p += s.qk;
+    dao = p; p += s.ao;
+    delta = p; p += s.lse;
+    dgu = p; p += s.gu;
+    dact = p; p += s.act;
+    ws_norm = p; p += al(sd_rmsnorm_bwd_workspace_bytes(s.M, s.h));
+    ws_qk = p; p += al(sd_qknorm_rope_bwd_workspace_bytes(s.M, s.Hq, s.Hkv));
+    total = p - p0;
+  }
+};
+
+#define RUN(call) do { int e__ = (call); if (e__) return e__; } while (0)
+
+}  // namespace
+
+extern "C" int sd_abi_version(void) { return 1; }
+
+extern "C" int64_t sd_qwen3_acts_bytes(const sd_qwen3_dims* d, int B, int T, int save) {
+  Sizes s(d, B, T);
+  if (save) return (int64_t)s.L * s.per_layer() + s.tail();
+  return s.per_layer() + s.x + s.tail();  // one layer's buffers + a ping-pong x
+}
+
+extern "C" int64_t sd_qwen3_bwd_scratch_bytes(const sd_qwen3_dims* d, int B, int T) {
+  Sizes s(d, B, T);
+  BwdScratch b(s, nullptr);
+  return b.total;
+}
+
+extern "C" int sd_qwen3_forward(const sd_qwen3_dims* d, const sd_qwen3_params* p, const int64_t* ids,
+                                const int32_t* kv_len, const void* cos_tab, const void* sin_tab, void* acts,
+                                int64_t acts_bytes, void* logits, int B, int T, int save, void* stream) {
+  if (d->head_dim != 128) return SD_ERR_UNSUPPORTED;
+  if (B <= 0 || T <= 0) return SD_ERR_SHAPE;
+  Sizes s(d, B, T);
+  if (acts_bytes < sd_qwen3_acts_bytes(d, B, T, save)) return SD_ERR_WORKSPACE;
+  char* base = (char*)acts;
+  const float scale = 0.08838834764831845f;  // 128^-1/2
+  char* tail = save ? base + (int64_t)s.L * s.per_layer() : base + s.per_layer() + s.x;
+  char* x_last = tail;
+  char* rstd_f = tail + s.x;
+  char* xn_f = rstd_f + s.rstd;
+  char* pong = base + s.per_layer();  // inference only
+
+  LayerActs a0 = carve(s, base);
+  RUN(sd_embedding_fwd(ids, p->embed, a0.x_in, s.M, s.h, s.V, stream));
+  char* x_cur = a0.x_in;
+  for (int l = 0; l < s.L; ++l) {
+    LayerActs a = carve(s, save ? base + (int64_t)l * s.per_layer() : base);
+    a.x_in = x_cur;
+    const sd_qwen3_layer& w = p->layers_host[l];
+    char* x_out;
+    if (save) x_out = (l + 1 < s.L) ? base + (int64_t)(l + 1) * s.per_layer() : x_last;
+    else x_out = (l + 1 < s.L) ? ((x_cur == pong) ? base : pong) : x_last;
+    RUN(sd_rmsnorm_fwd(a.x_in, w.ln1, a.xn1, (float*)a.rstd1, s.M, s.h, d->eps, stream));
+    RUN(sd_gemm_bf16(a.xn1, w.wqkv, a.qkv, nullptr, s.M, s.QKV, s.h, s.h, s.h, s.QKV, 0, 0, 0, stream));
+    RUN(sd_qknorm_rope_fwd(a.qkv, w.q_gain, w.k_gain, cos_tab, sin_tab, a.qk, s.M, T, s.Hq, s.Hkv, d->eps, stream));
+    RUN(sd_attn_fwd(a.qk, a.qk + (int64_t)s.QD * 2, a.qkv + (int64_t)(s.QD + s.KD) * 2, a.ao, (float*)a.lse, kv_len,
+                    s.QK, s.QK, s.QKV, s.QD, B, T, s.Hq, s.Hkv, 128, scale, stream));
+    RUN(sd_gemm_bf16(a.ao, w.wo, a.x_mid, a.x_in, s.M, s.h, s.QD, s.QD, s.QD, s.h, s.h, 0, 0, stream));
+    RUN(sd_rmsnorm_fwd(a.x_mid, w.ln2, a.xn2, (float*)a.rstd2, s.M, s.h, d->eps, stream));
+    RUN(sd_gemm_bf16(a.xn2, w.wgu, a.gu, nullptr, s.M, 2 * s.I, s.h, s.h, s.h, 2 * s.I, 0, 0, 0, stream));
+    RUN(sd_swiglu_fwd(a.gu, a.act, s.M, s.I, stream));
+    RUN(sd_gemm_bf16(a.act, w.wdown, x_out, a.x_mid, s.M, s.h, s.I, s.I, s.I, s.h, s.h, 0, 0, stream));
+    x_cur = x_out;
+  }
+  RUN(sd_rmsnorm_fwd(x_last, p->final_norm, xn_f, (float*)rstd_f, s.M, s.h, d->eps, stream));
+  if (logits) RUN(sd_gemm_bf16(xn_f, p->lm_head, logits, nullptr, s.M, s.V, s.h, s.h, s.h, s.V, 0, 0, 0, stream));
+  return 0;
+}
+
+extern "C" int sd_qwen3_backward(const sd_qwen3_dims* d, const sd_qwen3_params* p, const sd_qwen3_params* g,
+                                 const int64_t* ids, const int32_t* kv_len, const void* cos_tab, const void* sin_tab,
+                                 void* acts, int64_t acts_bytes, void* dlogits, void* scratch, int64_t scratch_bytes, int B,
+                                 int T, int accumulate, sd_stage_cb on_grads_ready, void* cb_user, void* stream) {
+  if (d->head_dim != 128) return SD_ERR_UNSUPPORTED;
+  Sizes s(d, B, T);
+  if (acts_bytes < sd_qwen3_acts_bytes(d, B, T, 1)) return SD_ERR_WORKSPACE;
+  BwdScratch b(s, (char*)scratch);
+  if (scratch_bytes < b.total) return SD_ERR_WORKSPACE;
+  char* base = (char*)acts;
+  const float scale = 0.08838834764831845f;
+  char* tail = base + (int64_t)s.L * s.per_layer();
+  char* x_last = tail;
+  char* rstd_f = tail + s.x;
+  char* xn_f = rstd_f + s.rstd;
+  const int acc = accumulate ? 1 : 0;
+#define ACC(ptr) (acc ? (const void*)(ptr) : (const void*)nullptr)
+
+  // lm_head: dxn = dlogits . W ; dW (+)= dlogits^T . xn_f
+  RUN(sd_gemm_bf16(dlogits, p->lm_head, b.dxn, nullptr, s.M, s.h, s.V, s.V, s.h, s.h, 0, 0, 1, stream));
+  RUN(sd_gemm_bf16(dlogits, xn_f, g->lm_head, ACC(g->lm_head), s.V, s.h, s.M, s.V, s.h, s.h, s.h, 1, 1, stream));
+  if (g->embed != g->lm_head && !acc)
+    if (hipMemsetAsync(g->embed, 0, (size_t)s.V * s.h * 2, (hipStream_t)stream) != hipSuccess) return SD_ERR_WORKSPACE;
+  RUN(sd_rmsnorm_bwd(b.dxn, x_last, p->final_norm, (const float*)rstd_f, nullptr, b.dx_a, g->final_norm, acc, b.ws_norm,
+                     s.M, s.h, stream));
+  if (on_grads_ready) on_grads_ready(SD_STAGE_HEAD, cb_user);
+  for (int l = s.L - 1; l >= 0; --l) {
+    LayerActs a = carve(s, base + (int64_t)l * s.per_layer());
+    const sd_qwen3_layer& w = p->layers_host[l];
+    const sd_qwen3_layer& gw = g->layers_host[l];
+    // MLP
+    RUN(sd_gemm_bf16(b.dx_a, w.wdown, b.dact, nullptr, s.M, s.I, s.h, s.h, s.I, s.I, 0, 0, 1, stream));
+    RUN(sd_gemm_bf16(b.dx_a, a.act, gw.wdown, ACC(gw.wdown), s.h, s.I, s.M, s.h, s.I, s.I, s.I, 1, 1, stream));
+    RUN(sd_swiglu_bwd(b.dact, a.gu, b.dgu, s.M, s.I, stream));
+    RUN(sd_gemm_bf16(b.dgu, w.wgu, b.dxn, nullptr, s.M, s.h, 2 * s.I, 2 * s.I, s.h, s.h, 0, 0, 1, stream));
+    RUN(sd_gemm_bf16(b.dgu, a.xn2, gw.wgu, ACC(gw.wgu), 2 * s.I, s.h, s.M, 2 * s.I, s.h, s.h, s.h, 1, 1, stream));
+    RUN(sd_rmsnorm_bwd(b.dxn, a.x_mid, w.ln2, (const float*)a.rstd2, b.dx_a, b.dx_b, gw.ln2, acc, b.ws_norm, s.M, s.h,
+                       stream));
+    // attention
+    RUN(sd_gemm_bf16(b.dx_b, w.wo, b.dao, nullptr, s.M, s.QD, s.h, s.h, s.QD, s.QD, 0, 0, 1, stream));
+    RUN(sd_gemm_bf16(b.dx_b, a.ao, gw.wo, ACC(gw.wo), s.h, s.QD, s.M, s.h, s.QD, s.QD, s.QD, 1, 1, stream));
+    RUN(sd_attn_bwd(a.qk, a.qk + (int64_t)s.QD * 2, a.qkv + (int64_t)(s.QD + s.KD) * 2, a.ao, b.dao, (const float*)a.lse,
+                    (float*)b.delta, b.dqk, b.dqk + (int64_t)s.QD * 2, b.dqkv + (int64_t)(s.QD + s.KD) * 2, kv_len, s.QK,
+                    s.QK, s.QKV, s.QD, s.QK, s.QK, s.QKV, B, T, s.Hq, s.Hkv, 128, scale, stream));
+    RUN(sd_qknorm_rope_bwd(b.dqk, a.qkv, w.q_gain, w.k_gain, cos_tab, sin_tab, b.dqkv, gw.q_gain, gw.k_gain, acc, b.ws_qk,
+                           s.M, T, s.Hq, s.Hkv, d->eps, stream));
+    RUN(sd_gemm_bf16(b.dqkv, w.wqkv, b.dxn, nullptr, s.M, s.h, s.QKV, s.QKV, s.h, s.h, 0, 0, 1, stream));
+    RUN(sd_gemm_bf16(b.dqkv, a.xn1, gw.wqkv, ACC(gw.wqkv), s.QKV, s.h, s.M, s.QKV, s.h, s.h, s.h, 1, 1, stream));
+    RUN(sd_rmsnorm_bwd(b.dxn, a.x_in, w.ln1, (const float*)a.rstd1, b.dx_b, b.dx_a, gw.ln1, acc, b.ws_norm, s.M, s.h,
+                       stream));
+    if (on_grads_ready) on_grads_ready(l, cb_user);
+  }
+  RUN(sd_embedding_bwd(ids, b.dx_a, g->embed, s.M, s.h, s.V, stream));
+  if (on_grads_ready) on_grads_ready(SD_STAGE_EMBED, cb_user);
+#undef ACC
+  return 0;
+}

@@ -1,0 +1,235 @@
+"""Tensor-level wrappers over the C ABI (one function per launcher in include/sd_hip.h).
+
+PyTorch is plumbing here: it owns device memory and the stream; every function takes CUDA(HIP)
+tensors, passes raw pointers + sizes + torch's current stream to libsd_hip.so and converts a
+non-zero status to an exception.  CPU tensors are rejected -- there is no fallback.
+"""
+from __future__ import annotations
+
+import torch
+
+from ._lib import check, load_lib
+
+BF16, F32 = 0, 1
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _need(t, dtype=None, name="tensor"):
+    if not t.is_cuda:
+        raise RuntimeError(f"speech_distill_amd: {name} must be a GPU tensor (no CPU fallback)")
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+    return t
+
+
+def _dt(t):
+    if t.dtype == torch.bfloat16:
+        return BF16
+    if t.dtype == torch.float32:
+        return F32
+    raise TypeError(f"unsupported dtype {t.dtype} (bf16 or fp32)")
+
+
+# ------------------------------------------------------------------------------------------ GEMM
+def gemm(a, b, trans_a=False, trans_b=False, residual=None, out=None):
+    """C = op(a) @ op(b) (+ residual).  trans_a: a is stored [K,M]; trans_b=False: b is [N,K]."""
+    _need(a, torch.bfloat16, "a"), _need(b, torch.bfloat16, "b")
+    K, M = (a.shape if trans_a else a.shape[::-1])
+    if trans_b:
+        Kb, N = b.shape
+    else:
+        N, Kb = b.shape
+    if Kb != K:
+        raise ValueError(f"gemm: contraction mismatch {K} vs {Kb}")
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=a.device)
+    r = None if residual is None else _need(residual, torch.bfloat16, "residual")
+    check(load_lib().sd_gemm_bf16(a.data_ptr(), b.data_ptr(), out.data_ptr(), _p(r), M, N, K, a.stride(0), b.stride(0),
+                                  out.stride(0), 0 if r is None else r.stride(0), int(trans_a), int(trans_b), _stream()),
+          "sd_gemm_bf16")
+    return out
+
+
+# ------------------------------------------------------------------------------------- elementwise
+def rmsnorm_fwd(x, w, eps=1e-6):
+    _need(x, torch.bfloat16, "x"), _need(w, torch.bfloat16, "w")
+    M, H = x.shape
+    y = torch.empty_like(x)
+    rstd = torch.empty(M, dtype=torch.float32, device=x.device)
+    check(load_lib().sd_rmsnorm_fwd(x.data_ptr(), w.data_ptr(), y.data_ptr(), rstd.data_ptr(), M, H, eps, _stream()),
+          "sd_rmsnorm_fwd")
+    return y, rstd
+
+
+def rmsnorm_bwd(dy, x, w, rstd, dres=None, dw=None, accumulate=False):
+    M, H = x.shape
+    lib = load_lib()
+    ws = torch.empty(lib.sd_rmsnorm_bwd_workspace_bytes(M, H), dtype=torch.uint8, device=x.device)
+    dx = torch.empty_like(x)
+    if dw is None:
+        dw = torch.zeros_like(w)
+    check(lib.sd_rmsnorm_bwd(dy.data_ptr(), x.data_ptr(), w.data_ptr(), rstd.data_ptr(), _p(dres), dx.data_ptr(),
+                             dw.data_ptr(), int(accumulate), ws.data_ptr(), M, H, _stream()), "sd_rmsnorm_bwd")
+    return dx, dw
+
+
+def rope_tables(T, device, theta=1e6, d=128):
+    """cos/sin [T,d] exactly as HF computes them (modeling_qwen3.py:113-137), rounded to bf16."""
+    inv = 1.0 / (theta ** (torch.arange(0, d, 2, dtype=torch.float32) / d))
+    fr = torch.arange(T, dtype=torch.float32)[:, None] * inv[None, :]
+    emb = torch.cat((fr, fr), dim=-1)
+    return emb.cos().to(torch.bfloat16).to(device), emb.sin().to(torch.bfloat16).to(device)
+
+
+def qknorm_rope_fwd(qkv, q_gain, k_gain, cos, sin, T, Hq, Hkv, eps=1e-6):
+    M = qkv.shape[0]
+    out = torch.empty(M, (Hq + Hkv) * 128, dtype=torch.bfloat16, device=qkv.device)
+    check(load_lib().sd_qknorm_rope_fwd(qkv.data_ptr(), q_gain.data_ptr(), k_gain.data_ptr(), cos.data_ptr(),
+                                        sin.data_ptr(), out.data_ptr(), M, T, Hq, Hkv, eps, _stream()),
+          "sd_qknorm_rope_fwd")
+    return out
+
+
+def qknorm_rope_bwd(dqk, qkv, q_gain, k_gain, cos, sin, T, Hq, Hkv, eps=1e-6):
+    M = qkv.shape[0]
+    lib = load_lib()
+    ws = torch.empty(lib.sd_qknorm_rope_bwd_workspace_bytes(M, Hq, Hkv), dtype=torch.uint8, device=qkv.device)
+    dqkv = torch.zeros_like(qkv)
+    dqg, dkg = torch.zeros_like(q_gain), torch.zeros_like(k_gain)
+    check(lib.sd_qknorm_rope_bwd(dqk.data_ptr(), qkv.data_ptr(), q_gain.data_ptr(), k_gain.data_ptr(), cos.data_ptr(),
+                                 sin.data_ptr(), dqkv.data_ptr(), dqg.data_ptr(), dkg.data_ptr(), 0, ws.data_ptr(), M, T,
+                                 Hq, Hkv, eps, _stream()), "sd_qknorm_rope_bwd")
+    return dqkv, dqg, dkg
+
+
+def swiglu_fwd(gu):
+    M, I2 = gu.shape
+    act = torch.empty(M, I2 // 2, dtype=torch.bfloat16, device=gu.device)
+    check(load_lib().sd_swiglu_fwd(gu.data_ptr(), act.data_ptr(), M, I2 // 2, _stream()), "sd_swiglu_fwd")
+    return act
+
+
+def swiglu_bwd(dact, gu):
+    M, I2 = gu.shape
+    dgu = torch.empty_like(gu)
+    check(load_lib().sd_swiglu_bwd(dact.data_ptr(), gu.data_ptr(), dgu.data_ptr(), M, I2 // 2, _stream()), "sd_swiglu_bwd")
+    return dgu
+
+
+def embedding_fwd(ids, E):
+    M = ids.numel()
+    V, H = E.shape
+    x = torch.empty(M, H, dtype=torch.bfloat16, device=E.device)
+    check(load_lib().sd_embedding_fwd(ids.data_ptr(), E.data_ptr(), x.data_ptr(), M, H, V, _stream()), "sd_embedding_fwd")
+    return x
+
+
+def embedding_bwd(ids, dx, dE):
+    V, H = dE.shape
+    check(load_lib().sd_embedding_bwd(ids.data_ptr(), dx.data_ptr(), dE.data_ptr(), ids.numel(), H, V, _stream()),
+          "sd_embedding_bwd")
+    return dE
+
+
+# --------------------------------------------------------------------------------------- attention
+def attn_fwd(q, k, v, B, T, Hq, Hkv, kv_len=None):
+    """q [B*T, Hq*128], k/v [B*T, Hkv*128] (any row stride, unit column stride)."""
+    M = B * T
+    o = torch.empty(M, Hq * 128, dtype=torch.bfloat16, device=q.device)
+    lse = torch.empty(B, Hq, T, dtype=torch.float32, device=q.device)
+    check(load_lib().sd_attn_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr(), _p(kv_len),
+                                 q.stride(0), k.stride(0), v.stride(0), o.stride(0), B, T, Hq, Hkv, 128, 128 ** -0.5,
+                                 _stream()), "sd_attn_fwd")
+    return o, lse
+
+
+def attn_bwd(q, k, v, o, do, lse, B, T, Hq, Hkv, kv_len=None):
+    delta = torch.empty_like(lse)
+    dq, dk, dv = torch.zeros_like(q), torch.zeros_like(k), torch.zeros_like(v)
+    check(load_lib().sd_attn_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(),
+                                 delta.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), _p(kv_len), q.stride(0),
+                                 k.stride(0), v.stride(0), o.stride(0), dq.stride(0), dk.stride(0), dv.stride(0), B, T, Hq,
+                                 Hkv, 128, 128 ** -0.5, _stream()), "sd_attn_bwd")
+    return dq, dk, dv
+
+
+# ------------------------------------------------------------------------------------ top-K / loss
+def logsoftmax_topk(logits, k, vocab_size=None):
+    """train.py:80-91: logits[..., :vocab] -> log_softmax -> topk(k) -> (fp16 values, int32 indices)."""
+    _need(logits, None, "logits")
+    lead = logits.shape[:-1]
+    Vt = logits.shape[-1]
+    V = Vt if vocab_size is None else min(int(vocab_size), Vt)
+    rows = logits.numel() // Vt
+    tv = torch.empty(*lead, k, dtype=torch.float16, device=logits.device)
+    ti = torch.empty(*lead, k, dtype=torch.int32, device=logits.device)
+    check(load_lib().sd_logsoftmax_topk(logits.data_ptr(), tv.data_ptr(), ti.data_ptr(), 0, rows, Vt, V, k, _dt(logits),
+                                        _stream()), "sd_logsoftmax_topk")
+    return tv, ti
+
+
+class KDLossFn(torch.autograd.Function):
+    """DistillationLoss.forward + its backward on the HIP kernels (distillation_loss.py:14-128)."""
+
+    @staticmethod
+    def forward(ctx, student_logits, labels, teacher_logits, top_v, top_i, speech_mask, temperature, alpha, inplace_grad):
+        s = _need(student_logits, None, "student_logits")
+        B, T, V = s.shape
+        dt = _dt(s)
+        lib = load_lib()
+        labels = _need(labels.to(torch.int64), torch.int64, "labels")
+        K = 0
+        if teacher_logits is not None:
+            teacher_logits = _need(teacher_logits.to(s.dtype), None, "teacher_logits")
+            if teacher_logits.shape != s.shape:
+                raise ValueError(f"teacher_logits {tuple(teacher_logits.shape)} != student_logits {tuple(s.shape)}")
+            top_v = top_i = None
+        elif top_v is not None and top_i is not None:
+            K = top_v.shape[-1]
+            # distillation_loss.py:78-91 moves the pre-extracted arrays to the student's device
+            top_v = top_v.to(device=s.device, dtype=torch.float16).contiguous()
+            top_i = top_i.to(device=s.device, dtype=torch.int32).contiguous()
+        else:
+            raise ValueError("Either teacher_logits or top_k must be provided")  # distillation_loss.py:120
+        mask = None
+        if speech_mask is not None:
+            mask = (speech_mask.to(s.device) != 0).to(torch.uint8).contiguous()
+        stats = torch.empty(lib.sd_kdloss_stats_bytes(B, T), dtype=torch.uint8, device=s.device)
+        out = torch.empty(8, dtype=torch.float32, device=s.device)
+        check(lib.sd_kdloss_fwd(s.data_ptr(), _p(teacher_logits), _p(top_v), _p(top_i), labels.data_ptr(), _p(mask),
+                                stats.data_ptr(), out.data_ptr(), B, T, V, K, float(temperature), float(alpha), dt,
+                                _stream()), "sd_kdloss_fwd")
+        ctx.save_for_backward(s, labels, teacher_logits, top_v, top_i, stats, out)
+        ctx.cfg = (B, T, V, K, float(temperature), float(alpha), dt, bool(inplace_grad))
+        ctx.mark_non_differentiable(out)
+        return out[0].clone(), out
+
+    @staticmethod
+    def backward(ctx, g_total, _g_out):
+        s, labels, teacher_logits, top_v, top_i, stats, out = ctx.saved_tensors
+        B, T, V, K, temperature, alpha, dt, inplace = ctx.cfg
+        grad = s if inplace else torch.empty_like(s)
+        go = g_total.to(torch.float32).reshape(1).contiguous()
+        check(load_lib().sd_kdloss_bwd(s.data_ptr(), _p(teacher_logits), _p(top_v), _p(top_i), labels.data_ptr(),
+                                       stats.data_ptr(), out.data_ptr(), go.data_ptr(), grad.data_ptr(), B, T, V, K,
+                                       temperature, alpha, dt, _stream()), "sd_kdloss_bwd")
+        return grad, None, None, None, None, None, None, None, None
+
+
+# --------------------------------------------------------------------------------------- optimizer
+def sumsq(x, out):
+    check(load_lib().sd_sumsq_bf16(x.data_ptr(), x.numel(), out.data_ptr(), _stream()), "sd_sumsq_bf16")
+
+
+def adamw_(p, g, m, v, lr, beta1, beta2, eps, wd, step, grad_sumsq=None, max_norm=0.0):
+    check(load_lib().sd_adamw_bf16(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, beta1, beta2,
+                                   eps, wd, step, _p(grad_sumsq), max_norm, _stream()), "sd_adamw_bf16")

@@ -1,0 +1,71 @@
+"""Drop-in for the reference's ``DistillationTrainer`` (train.py:24-116): same constructor keywords,
+same ``compute_loss`` contract, same three logged sub-losses, the HIP kernels underneath.
+
+Step body (train.py:43-116):  pop the teacher / extra keys  ->  student forward (labels still in the
+inputs, as in the reference)  ->  pop labels  ->  teacher no-grad forward unless pre-extracted top-K is
+present  ->  on-the-fly log-softmax + top-K unless the teacher is quantized or top_k <= 0  ->
+DistillationLoss  ->  log {student_loss, teacher_loss, distill_loss} when
+``state.global_step % args.logging_steps == 0``  ->  ``loss`` or ``(loss, outputs)``.
+"""
+import torch
+from transformers import Trainer
+
+from . import ops
+from .distillation_loss import DistillationLoss
+from .qwen3 import HipQwen3ForCausalLM
+
+
+class DistillationTrainer(Trainer):
+    def __init__(self, *args, teacher_model=None, temperature=2.0, alpha=0.5, top_k=100, is_quantized_teacher=False,
+                 **kwargs):
+        super().__init__(*args, **kwargs)
+        self.teacher_model = teacher_model
+        if self.teacher_model is not None:
+            self.teacher_model.eval()
+        self.top_k = top_k
+        self.distill_loss_fn = DistillationLoss(temperature=temperature, alpha=alpha)
+        self.is_quantized_teacher = is_quantized_teacher
+        # compute back-ends; the product ones are the HIP kernels (tests may inject a checker here)
+        self._extract_topk = ops.logsoftmax_topk
+        self.tokens_seen = 0
+
+    def compute_loss(self, model, inputs, return_outputs=False, **kwargs):
+        teacher_input_ids = inputs.pop("teacher_input_ids", None)
+        teacher_attention_mask = inputs.pop("teacher_attention_mask", None)
+        speech_mask = inputs.pop("speech_token_mask", None)
+        teacher_top_k_v = inputs.pop("teacher_top_k_v", None)
+        teacher_top_k_i = inputs.pop("teacher_top_k_i", None)
+
+        outputs = model(**inputs)  # train.py:54
+        student_logits = outputs.logits
+        labels = inputs.pop("labels", None)
+
+        teacher_logits = None
+        if teacher_top_k_v is None and self.teacher_model is not None:  # train.py:60-69
+            with torch.no_grad():
+                if teacher_input_ids is not None:
+                    teacher_outputs = self.teacher_model(input_ids=teacher_input_ids,
+                                                         attention_mask=teacher_attention_mask)
+                else:
+                    teacher_outputs = self.teacher_model(**inputs)
+                teacher_logits = teacher_outputs.logits
+
+        if (teacher_logits is not None and teacher_top_k_v is None and not self.is_quantized_teacher
+                and self.top_k > 0):  # train.py:74-94
+            with torch.no_grad():
+                teacher_top_k_v, teacher_top_k_i = self._extract_topk(teacher_logits, self.top_k,
+                                                                      student_logits.size(-1))
+            teacher_logits = None
+
+        if isinstance(self.distill_loss_fn, DistillationLoss):
+            self.distill_loss_fn.inplace_grad = (not return_outputs) and isinstance(model, HipQwen3ForCausalLM)
+        loss, task_loss, distill_loss, teacher_loss = self.distill_loss_fn(
+            student_logits=student_logits, labels=labels, teacher_logits=teacher_logits,
+            teacher_top_k_v=teacher_top_k_v, teacher_top_k_i=teacher_top_k_i, speech_token_mask=speech_mask)
+
+        if self.state.global_step % self.args.logging_steps == 0:  # train.py:107-114
+            # one device->host sync for the three scalars instead of three .item() calls
+            vals = torch.stack([task_loss.detach().float(), teacher_loss.detach().float(),
+                                distill_loss.detach().float()]).tolist()
+            self.log({"student_loss": vals[0], "teacher_loss": vals[1], "distill_loss": vals[2]})
+        return (loss, outputs) if return_outputs else loss

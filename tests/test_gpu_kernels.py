@@ -1,0 +1,317 @@
+"""-m gpu parity tests: every HIP launcher (through the C ABI / ctypes) against the CPU oracle, the
+golden fixtures generated from the reference, and a plain fp32/fp64 torch statement of the op.
+
+Tolerances (stated per test): bf16 kernels are compared with an fp64 evaluation of the SAME bf16
+inputs; one bf16 rounding of the output is 2^-9 relative (3.9e-3 max), so max-norm bounds are a few
+times that and rms bounds ~2e-3.  Integer-valued inputs must come out exact.
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import distill_loss, qwen3
+    return type("O", (), {"L": distill_loss, "Q": qwen3})
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import speech_distill_amd.ops as ops_
+    ops_.load_lib()
+    return ops_
+
+
+from gpu_util import bf, check_close, dev, record, to_dev  # noqa: E402
+
+
+# ------------------------------------------------------------------------------------------- GEMM
+def _gemm_ref(a, b, ta, tb, r=None):
+    A = a.double().T if ta else a.double()
+    Bm = b.double() if tb else b.double().T
+    c = A @ Bm
+    if r is not None:
+        c = c + r.double()
+    return c
+
+
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, True), (True, False)])
+def test_gemm_exact_integers(ops, ta, tb):
+    """Small integers are exact in bf16 and fp32: any layout / fragment-order mistake shows as a wrong integer."""
+    g = torch.Generator().manual_seed(1)
+    M, N, K = 200, 136, 72
+    a = torch.randint(-3, 4, (K, M) if ta else (M, K), generator=g).float()
+    b = torch.randint(-3, 4, (K, N) if tb else (N, K), generator=g).float()
+    a[0, :] += 1.0  # asymmetric
+    got = ops.gemm(to_dev(bf(a)), to_dev(bf(b)), ta, tb).float().cpu()
+    ref = _gemm_ref(a, b, ta, tb).float()
+    bad = (got != ref).nonzero()
+    record(f"gemm_exact_ta{int(ta)}_tb{int(tb)}", n_bad=int(bad.shape[0]))
+    assert bad.shape[0] == 0, f"{bad.shape[0]} wrong entries, first {bad[:5].tolist()} got {got[tuple(bad[0])]} ref {ref[tuple(bad[0])]}"
+
+
+@pytest.mark.parametrize("M,N,K,ta,tb,res", [
+    (128, 128, 64, False, False, False), (2048, 1024, 1024, False, False, True), (300, 520, 128, False, False, False),
+    (2048, 1024, 4096, False, True, False), (333, 256, 520, False, True, True),
+    (4096, 1024, 2048, True, True, False), (520, 128, 48, True, True, True), (1000, 640, 160, True, True, False),
+])
+def test_gemm_random(ops, M, N, K, ta, tb, res):
+    g = torch.Generator().manual_seed(M + N + K)
+    a = bf(torch.randn((K, M) if ta else (M, K), generator=g))
+    b = bf(torch.randn((K, N) if tb else (N, K), generator=g))
+    r = bf(torch.randn(M, N, generator=g) * 8) if res else None
+    got = ops.gemm(to_dev(a), to_dev(b), ta, tb, residual=None if r is None else to_dev(r))
+    ref = _gemm_ref(a.float(), b.float(), ta, tb, None if r is None else r.float())
+    check_close(f"gemm_{M}x{N}x{K}_ta{int(ta)}tb{int(tb)}r{int(res)}", got, ref, 6e-3, 3e-3)
+
+
+def test_gemm_accumulate_in_place(ops):
+    g = torch.Generator().manual_seed(5)
+    a, b = bf(torch.randn(160, 256, generator=g)), bf(torch.randn(160, 136, generator=g))
+    c0 = bf(torch.randn(256, 136, generator=g) * 4)
+    c = to_dev(c0.clone())
+    ops.gemm(to_dev(a), to_dev(b), True, True, residual=c, out=c)
+    check_close("gemm_accumulate", c, _gemm_ref(a.float(), b.float(), True, True, c0.float()), 6e-3, 3e-3)
+
+
+# ------------------------------------------------------------------------------------ row kernels
+@pytest.mark.parametrize("M,H", [(64, 128), (37, 1024), (256, 2048)])
+def test_rmsnorm_fwd_bwd(ops, O, M, H):
+    g = torch.Generator().manual_seed(M)
+    x, w = bf(torch.randn(M, H, generator=g) * 2), bf(1 + 0.2 * torch.randn(H, generator=g))
+    dy, dres = bf(torch.randn(M, H, generator=g)), bf(torch.randn(M, H, generator=g))
+    y, rstd = ops.rmsnorm_fwd(to_dev(x), to_dev(w))
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    yr = wr * (xr * torch.rsqrt(xr.pow(2).mean(-1, keepdim=True) + 1e-6))
+    check_close(f"rmsnorm_fwd_{M}x{H}", y, yr, 1.2e-2, 3e-3)
+    (yr * dy.double()).sum().backward()
+    dx, dw = ops.rmsnorm_bwd(to_dev(dy), to_dev(x), to_dev(w), rstd, dres=to_dev(dres))
+    check_close(f"rmsnorm_bwd_dx_{M}x{H}", dx, xr.grad + dres.double(), 1.2e-2, 3e-3)
+    check_close(f"rmsnorm_bwd_dw_{M}x{H}", dw, wr.grad, 1.2e-2, 4e-3)
+
+
+@pytest.mark.parametrize("B,T,Hq,Hkv", [(2, 24, 4, 2), (1, 130, 2, 1)])
+def test_qknorm_rope_fwd_bwd(ops, O, B, T, Hq, Hkv):
+    g = torch.Generator().manual_seed(T)
+    M = B * T
+    qkv = bf(torch.randn(M, (Hq + 2 * Hkv) * 128, generator=g))
+    qg, kg = bf(1 + 0.2 * torch.randn(128, generator=g)), bf(1 + 0.2 * torch.randn(128, generator=g))
+    cos, sin = ops.rope_tables(T, dev())
+    out = ops.qknorm_rope_fwd(to_dev(qkv), to_dev(qg), to_dev(kg), cos, sin, T, Hq, Hkv)
+    x = qkv.double().requires_grad_(True)
+    qgr, kgr = qg.double().requires_grad_(True), kg.double().requires_grad_(True)
+    q = x[:, :Hq * 128].view(B, T, Hq, 128)
+    k = x[:, Hq * 128:(Hq + Hkv) * 128].view(B, T, Hkv, 128)
+    c64, s64 = cos.cpu().double(), sin.cpu().double()
+
+    def nr(t, gain):
+        t = gain * (t * torch.rsqrt(t.pow(2).mean(-1, keepdim=True) + 1e-6))
+        return O.Q.apply_rope(t.transpose(1, 2), c64, s64).transpose(1, 2)
+    ref = torch.cat([nr(q, qgr).reshape(M, -1), nr(k, kgr).reshape(M, -1)], -1)
+    check_close(f"qknorm_rope_fwd_T{T}", out, ref, 1.5e-2, 4e-3)
+    dout = bf(torch.randn(ref.shape, generator=g))
+    (ref * dout.double()).sum().backward()
+    dqkv, dqg, dkg = ops.qknorm_rope_bwd(to_dev(dout), to_dev(qkv), to_dev(qg), to_dev(kg), cos, sin, T, Hq, Hkv)
+    check_close(f"qknorm_rope_bwd_dx_T{T}", dqkv[:, :(Hq + Hkv) * 128], x.grad[:, :(Hq + Hkv) * 128], 1.5e-2, 4e-3)
+    check_close(f"qknorm_rope_bwd_dqg_T{T}", dqg, qgr.grad, 1.5e-2, 5e-3)
+    check_close(f"qknorm_rope_bwd_dkg_T{T}", dkg, kgr.grad, 1.5e-2, 5e-3)
+
+
+def test_swiglu_fwd_bwd(ops):
+    g = torch.Generator().manual_seed(3)
+    gu, dact = bf(torch.randn(70, 512, generator=g) * 2), bf(torch.randn(70, 256, generator=g))
+    x = gu.double().requires_grad_(True)
+    ref = torch.nn.functional.silu(x[:, :256]) * x[:, 256:]
+    check_close("swiglu_fwd", ops.swiglu_fwd(to_dev(gu)), ref, 8e-3, 3e-3)
+    (ref * dact.double()).sum().backward()
+    check_close("swiglu_bwd", ops.swiglu_bwd(to_dev(dact), to_dev(gu)), x.grad, 8e-3, 3e-3)
+
+
+def test_embedding_fwd_bwd(ops):
+    g = torch.Generator().manual_seed(4)
+    V, H, M = 520, 256, 96
+    E = bf(torch.randn(V, H, generator=g))
+    ids = torch.randint(0, V, (M,), generator=g)
+    ids[10:20] = ids[0]  # duplicates
+    x = ops.embedding_fwd(to_dev(ids), to_dev(E))
+    assert torch.equal(x.cpu(), E[ids])
+    dx = bf(torch.randn(M, H, generator=g))
+    dE0 = bf(torch.randn(V, H, generator=g))
+    dE = ops.embedding_bwd(to_dev(ids), to_dev(dx), to_dev(dE0.clone()))
+    ref = dE0.double().index_add(0, ids, dx.double())
+    check_close("embedding_bwd", dE, ref, 8e-3, 2e-3)
+
+
+# -------------------------------------------------------------------------------------- attention
+@pytest.mark.parametrize("B,T,Hq,Hkv,pad", [(2, 128, 4, 2, False), (1, 200, 2, 1, True), (2, 64, 2, 2, True),
+                                            (1, 512, 4, 2, False), (1, 40, 2, 1, False)])
+def test_attention_fwd_bwd(ops, O, B, T, Hq, Hkv, pad):
+    g = torch.Generator().manual_seed(T + Hq)
+    M = B * T
+    q, k, v = (bf(torch.randn(M, h * 128, generator=g)) for h in (Hq, Hkv, Hkv))
+    do = bf(torch.randn(M, Hq * 128, generator=g))
+    kv_len = None
+    if pad:
+        kv_len = torch.tensor([max(1, T - 7 - 11 * b) for b in range(B)], dtype=torch.int32)
+    o, lse = ops.attn_fwd(to_dev(q), to_dev(k), to_dev(v), B, T, Hq, Hkv, None if kv_len is None else to_dev(kv_len))
+    qr, kr, vr = (t.double().requires_grad_(True) for t in (q, k, v))
+    ref = O.Q.attention(qr.view(B, T, Hq, 128).transpose(1, 2), kr.view(B, T, Hkv, 128).transpose(1, 2),
+                        vr.view(B, T, Hkv, 128).transpose(1, 2), None if kv_len is None else kv_len.long())
+    ref = ref.transpose(1, 2).reshape(M, Hq * 128)
+    check_close(f"attn_fwd_B{B}T{T}H{Hq}/{Hkv}p{int(pad)}", o, ref, 1.5e-2, 4e-3)
+    (ref * do.double()).sum().backward()
+    dq, dk, dv = ops.attn_bwd(to_dev(q), to_dev(k), to_dev(v), o, to_dev(do), lse, B, T, Hq, Hkv,
+                              None if kv_len is None else to_dev(kv_len))
+    check_close(f"attn_bwd_dq_B{B}T{T}p{int(pad)}", dq, qr.grad, 2e-2, 6e-3)
+    check_close(f"attn_bwd_dk_B{B}T{T}p{int(pad)}", dk, kr.grad, 2e-2, 6e-3)
+    check_close(f"attn_bwd_dv_B{B}T{T}p{int(pad)}", dv, vr.grad, 2e-2, 6e-3)
+
+
+# ------------------------------------------------------------------------------------------ top-K
+def test_topk_golden_fp32(ops):
+    """G2: the reference's own train.py:80-91 outputs (fp32 logits, no ties) must be reproduced bit for bit
+    in the indices and to one fp16 ulp in the values."""
+    z = load_golden("g2_extract.npz")
+    for name in "abc":
+        Vs, K = [int(x) for x in z[f"{name}_meta"]]
+        v, i = ops.logsoftmax_topk(to_dev(torch.from_numpy(z[f"{name}_logits"])), K, Vs)
+        np.testing.assert_array_equal(i.cpu().numpy(), z[f"{name}_i"], err_msg=name)
+        dv = np.abs(v.cpu().float().numpy() - z[f"{name}_v"].astype(np.float32))
+        record(f"topk_golden_{name}", max_abs=float(dv.max()))
+        assert dv.max() <= 1e-2 * 0 + 8e-3, f"{name}: values differ by {dv.max()}"
+
+
+@pytest.mark.parametrize("rows,V,K,dtype", [(5, 4096, 128, "bf16"), (3, 159488, 128, "bf16"), (4, 1000, 100, "bf16"),
+                                            (2, 159488, 100, "fp32"), (3, 64, 64, "bf16")])
+def test_topk_vs_oracle(ops, O, rows, V, K, dtype):
+    """bf16 logits have many exact ties: values must match exactly, indices as a set modulo ties, ties to the lowest index."""
+    g = torch.Generator().manual_seed(V + K)
+    x = torch.randn(rows, V, generator=g) * 3
+    x = bf(x) if dtype == "bf16" else x
+    v, i = ops.logsoftmax_topk(to_dev(x), K)
+    rv, ri = O.L.extract_topk(x.float(), K)
+    np.testing.assert_array_equal(i.cpu().numpy(), ri.numpy())
+    d = (v.cpu().float() - rv.float()).abs().max()
+    record(f"topk_{rows}x{V}_{dtype}", max_abs=float(d))
+    assert d <= 8e-3
+
+
+def test_topk_all_equal_row(ops):
+    x = bf(torch.zeros(2, 1024))
+    x[1, 500] = 1.0
+    v, i = ops.logsoftmax_topk(to_dev(x), 16)
+    assert i[0].cpu().tolist() == list(range(16))
+    assert i[1].cpu().tolist() == [500] + list(range(15))
+
+
+# ------------------------------------------------------------------------------------------- loss
+G1 = sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "g1_loss_*.npz")))
+
+
+@pytest.mark.parametrize("fname", G1)
+def test_loss_golden(ops, fname):
+    """G1: the reference DistillationLoss's own outputs.  fp32 fixtures: losses to 2e-5, gradient to 1e-4 of
+    its max; bf16 fixtures (reference ran log-softmax in bf16): 3e-2 (SURVEY.md section 8d tolerance)."""
+    from speech_distill_amd import DistillationLoss
+    z = load_golden(fname)
+    is_bf16 = str(z["dtype"]) == "bf16"
+    cast = bf if is_bf16 else (lambda t: t)
+    labels = to_dev(torch.from_numpy(z["labels"]))
+    sm = to_dev(torch.from_numpy(z["speech_mask"])) if "speech_mask" in z.files else None
+    for key in [k[:-7] for k in z.files if k.endswith("_losses")]:
+        mode, Tm, al = key.split("_")
+        s = to_dev(cast(torch.from_numpy(z["student"]))).requires_grad_(True)
+        kw = (dict(teacher_logits=to_dev(cast(torch.from_numpy(z["teacher"])))) if mode == "dense" else
+              dict(teacher_top_k_v=to_dev(torch.from_numpy(z["top_v"])), teacher_top_k_i=to_dev(torch.from_numpy(z["top_i"]))))
+        fn = DistillationLoss(temperature=float(Tm[1:]), alpha=float(al[1:]))
+        out = fn(s, labels, speech_token_mask=sm, **kw)
+        got = np.array([float(x) for x in out])
+        ref = z[key + "_losses"]
+        rtol = 3e-2 if is_bf16 else 2e-5
+        record(f"loss_{fname}_{key}", got=got.tolist(), ref=ref.tolist())
+        np.testing.assert_allclose(got, ref, rtol=rtol, atol=2e-6, err_msg=key)
+        out[0].backward()
+        gref = torch.from_numpy(z[key + "_grad"])
+        if float(gref.abs().max()) == 0:
+            assert float(s.grad.abs().max()) == 0
+        else:
+            check_close(f"lossgrad_{fname}_{key}", s.grad, gref, 3e-2 if is_bf16 else 1e-4)
+
+
+def test_loss_no_teacher_raises(ops):
+    from speech_distill_amd import DistillationLoss
+    with pytest.raises(ValueError, match="Either teacher_logits or top_k must be provided"):
+        DistillationLoss()(to_dev(torch.randn(1, 4, 64)), to_dev(torch.tensor([[1, 2, 3, 4]])))
+
+
+@pytest.mark.parametrize("mode", ["sparse", "dense"])
+def test_loss_full_vocab_vs_oracle(ops, O, mode):
+    """V = 159 488 (the real vocab), bf16 logits, against the fp64 oracle on the same bf16 values."""
+    from speech_distill_amd import DistillationLoss
+    g = torch.Generator().manual_seed(7)
+    B, T, V, K = 2, 6, 159488, 128
+    s = bf(torch.randn(B, T, V, generator=g) * 2)
+    t = bf(torch.randn(B, T, V, generator=g) * 2)
+    labels = torch.randint(152927, V, (B, T), generator=g)
+    labels[:, :2] = -100
+    tv, ti = O.L.extract_topk(t.float(), K)
+    kw_o = dict(teacher_logits=t.float()) if mode == "dense" else dict(teacher_top_k_v=tv, teacher_top_k_i=ti)
+    ref = O.L.distill_loss(s.float(), labels, temperature=2.0, alpha=0.5, return_grad=True, **kw_o)
+    sd = to_dev(s).requires_grad_(True)
+    kw = dict(teacher_logits=to_dev(t)) if mode == "dense" else dict(teacher_top_k_v=to_dev(tv), teacher_top_k_i=to_dev(ti))
+    out = DistillationLoss(2.0, 0.5)(sd, to_dev(labels), **kw)
+    got = np.array([float(x) for x in out])
+    np.testing.assert_allclose(got, [float(x) for x in ref[:4]], rtol=2e-5, atol=1e-6)
+    out[0].backward()
+    # gradient is stored in bf16: one rounding of each entry
+    check_close(f"lossgrad_fullV_{mode}", sd.grad, ref[4], 8e-3, 3e-3)
+    # size-independent property: every valid row's gradient sums to zero (softmax rows sum to 1, sum q = 1)
+    rs = sd.grad.float().sum(-1).abs().max()
+    record(f"lossgrad_rowsum_{mode}", max_rowsum=float(rs))
+    assert float(rs) < 2e-3
+
+
+def test_loss_inplace_grad_matches(ops):
+    from speech_distill_amd import DistillationLoss
+    g = torch.Generator().manual_seed(9)
+    s = bf(torch.randn(2, 9, 1000, generator=g))
+    labels = torch.randint(0, 1000, (2, 9), generator=g)
+    tv, ti = torch.topk(torch.log_softmax(torch.randn(2, 9, 1000, generator=g), -1), 50)
+    a = to_dev(s).requires_grad_(True)
+    b_leaf = to_dev(s).requires_grad_(True)
+    b = b_leaf * 1  # non-leaf so the buffer may be overwritten
+    DistillationLoss(2.0, 0.5)(a, to_dev(labels), teacher_top_k_v=to_dev(tv.half()), teacher_top_k_i=to_dev(ti.int()))[0].backward()
+    DistillationLoss(2.0, 0.5, inplace_grad=True)(b, to_dev(labels), teacher_top_k_v=to_dev(tv.half()),
+                                                  teacher_top_k_i=to_dev(ti.int()))[0].backward()
+    assert torch.equal(a.grad, b_leaf.grad)
+
+
+# -------------------------------------------------------------------------------------- optimizer
+def test_adamw_and_clip(ops):
+    g = torch.Generator().manual_seed(11)
+    n = 100003
+    p, gr = bf(torch.randn(n, generator=g)), bf(torch.randn(n, generator=g))
+    m, v = bf(torch.randn(n, generator=g) * 0.1), bf(torch.rand(n, generator=g) * 0.1)
+    pd, gd, md, vd = (to_dev(t.clone()) for t in (p, gr, m, v))
+    ss = torch.zeros(1, device=dev())
+    ops.sumsq(gd, ss)
+    np.testing.assert_allclose(float(ss), float(gr.double().pow(2).sum()), rtol=1e-4)
+    lr, b1, b2, eps, wd, step, mx = 1e-2, 0.9, 0.999, 1e-8, 0.01, 3, 1.0
+    ops.adamw_(pd, gd, md, vd, lr, b1, b2, eps, wd, step, ss, mx)
+    clip = min(1.0, mx / (float(gr.double().pow(2).sum().sqrt()) + 1e-6))
+    P, G, Mo, Vo = p.double(), gr.double() * clip, m.double(), v.double()
+    P = P * (1 - lr * wd)
+    Mo = b1 * Mo + (1 - b1) * G
+    Vo = b2 * Vo + (1 - b2) * G * G
+    P = P - lr / (1 - b1 ** step) * Mo / (Vo.sqrt() / (1 - b2 ** step) ** 0.5 + eps)
+    check_close("adamw_p", pd, P, 8e-3, 3e-3)
+    check_close("adamw_m", md, Mo, 8e-3, 3e-3)
+    check_close("adamw_v", vd, Vo, 8e-3, 3e-3)
