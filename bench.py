@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""bench.py -- distill-step tokens/sec (BASELINE.json metric) on N MI355X of one node.
+
+One "step" = one Stage-2 distillation micro-step on one synthetic pre-processed batch, exactly the
+body of the reference's DistillationTrainer.compute_loss + backward (train.py:43-116, HF
+trainer.py:1961): student (Qwen3-0.6B shape, vocab 159 488) forward, frozen teacher (SoulX-Podcast-
+1.7B shape) no-grad forward, on-the-fly log-softmax + top-128, temperature-scaled KL + CE loss,
+student backward; for N > 1 plus the bucketed RCCL all-reduce (avg) of the student gradients,
+overlapped with backward.  Workload = BASELINE config 2 per GPU: bf16, seq_len 512, batch 4
+(config 3 = 8 ranks of it, weak scaling).  Inputs are resident in HBM before the timed region.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract in the round brief) with two extra objects:
+  roofline     -- the dominant kernel (by time) of the step, measured live with HIP events recorded on
+                  the launch stream inside the timed region: algorithmic FLOPs / its total duration
+                  against the dense bf16 MFMA peak (2.5 PFLOP/s);
+  cpu_baseline -- the CPU oracle (a port of the reference's CPU path, pinned to it by fixtures) timed
+                  on this box's host cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_PEAK_TFLOPS = 2500.0  # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+SPEECH_LO, VOCAB = 152927, 159488
+KERNEL_NAMES = {"gemm_nt": "gemm_bf16_kernel<false,false,*>", "gemm_nn": "gemm_bf16_kernel<false,true,*>",
+                "gemm_tn": "gemm_bf16_kernel<true,true,*>"}
+
+
+def synthetic_batch(B, T, rank, device):
+    """uniform ids, 25 % text prefix masked to -100, then speech_bos, then speech ids."""
+    g = torch.Generator().manual_seed(1234 + rank)
+    ids = torch.randint(0, VOCAB, (B, T), generator=g)
+    n_text = T // 4
+    ids[:, n_text] = SPEECH_LO  # speech_bos stand-in
+    ids[:, n_text + 1:] = torch.randint(SPEECH_LO, VOCAB, (B, T - n_text - 1), generator=g)
+    labels = ids.clone()
+    labels[:, :n_text] = -100
+    return {"input_ids": ids.to(device), "attention_mask": torch.ones(B, T, dtype=torch.long, device=device),
+            "labels": labels.to(device), "teacher_input_ids": ids.to(device),
+            "teacher_attention_mask": torch.ones(B, T, dtype=torch.long, device=device)}
+
+
+def cpu_baseline(sample_T, threads):
+    """Oracle (port of the reference CPU path) on host cores: full-shape models, 1 sequence."""
+    from oracle import qwen3 as Q
+    from oracle import step as S
+    torch.set_num_threads(threads)
+    g = torch.Generator().manual_seed(1234)
+    sw = {}
+    tw = {}
+    for shape, dst, seed in ((Q.STUDENT_06B, sw, 0), (Q.TEACHER_17B, tw, 1)):
+        gg = torch.Generator().manual_seed(seed)
+        for name, shp in Q.param_names(shape):
+            dst[name] = torch.ones(shp) if len(shp) == 1 else torch.empty(shp).normal_(0, 0.02, generator=gg)
+    ids = torch.randint(0, VOCAB, (1, sample_T), generator=g)
+    ids[:, sample_T // 4:] = torch.randint(SPEECH_LO, VOCAB, (1, sample_T - sample_T // 4), generator=g)
+    labels = ids.clone()
+    labels[:, : sample_T // 4] = -100
+    batch = {"input_ids": ids, "attention_mask": torch.ones_like(ids), "labels": labels}
+    t0 = time.time()
+    out = S.distill_step(sw, Q.STUDENT_06B, tw, Q.TEACHER_17B, batch, 2.0, 0.5, top_k=128, acc=torch.float32)
+    dt = time.time() - t0
+    return {"value": sample_T / dt, "unit": "tokens/s", "cores": threads, "kind": "port",
+            "sample": f"1 sequence x {sample_T} tokens (of the 4 x 512 batch), full-shape teacher+student, fp32, "
+                      f"one micro-step incl. backward, {dt:.1f} s",
+            "loss": float(out["total"])}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=4)
+    ap.add_argument("--seq-len", type=int, default=512)
+    ap.add_argument("--top-k", type=int, default=128)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prof", action="store_true", help="do not record per-launch HIP events in the timed region")
+    ap.add_argument("--cpu-sample-tokens", type=int, default=512)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+
+    import speech_distill_amd as sda
+    from speech_distill_amd import ddp, ops
+    sda.load_lib()  # raises if libsd_hip.so is missing: no fallback
+
+    student = sda.HipQwen3ForCausalLM(sda.Qwen3Dims.student_06b(), device=dev, init_std=0)
+    teacher = sda.HipQwen3ForCausalLM(sda.Qwen3Dims.teacher_17b(), device=dev, init_std=0)
+    for m, seed in ((student, 0), (teacher, 1)):  # HF default init N(0, 0.02), same on every rank
+        gen = torch.Generator(device=dev).manual_seed(seed)
+        m.flat.normal_(0.0, 0.02, generator=gen)
+        for p in m._params.values():
+            if p.dim() == 1:
+                p.data.fill_(1.0)
+    teacher.eval().requires_grad_(False)
+    loss_fn = sda.DistillationLoss(temperature=2.0, alpha=0.5, inplace_grad=True)
+    reducer = ddp.attach(student) if world > 1 else None
+    batch = synthetic_batch(args.batch, args.seq_len, rank, dev)
+
+    def step():
+        student.zero_grad()
+        logits = student(input_ids=batch["input_ids"], attention_mask=batch["attention_mask"],
+                         labels=batch["labels"]).logits                                     # train.py:54
+        with torch.no_grad():
+            t_logits = teacher(input_ids=batch["teacher_input_ids"],
+                               attention_mask=batch["teacher_attention_mask"]).logits       # train.py:60-69
+            tv, ti = ops.logsoftmax_topk(t_logits, args.top_k, logits.size(-1))             # train.py:80-91
+            del t_logits
+        total, task, distill, teach = loss_fn(logits, batch["labels"], teacher_top_k_v=tv, teacher_top_k_i=ti)
+        total.backward()                                                                    # HF trainer.py:1961
+        return total, task, distill, teach
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = step()
+    barrier()
+    if not args.no_prof:
+        ops.prof_begin()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = None if args.no_prof else ops.prof_end()
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax)
+    losses = [float(x) for x in out]
+
+    if rank == 0:
+        tokens = world * args.batch * args.seq_len * args.steps
+        from oracle.qwen3 import STUDENT_06B, TEACHER_17B, flops_per_token
+        f_tok = 3 * flops_per_token(STUDENT_06B, args.seq_len) + flops_per_token(TEACHER_17B, args.seq_len)
+        res = {
+            "metric": "distill-step tokens/sec (student seq_len=512)", "value": tokens / dt, "unit": "tokens/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"BASELINE config {2 if world == 1 else 3}: Qwen3-0.6B-shape student + SoulX-1.7B-shape "
+                                   f"teacher (random init), V=159488, batch {args.batch}/GPU, seq_len {args.seq_len}, "
+                                   f"top_k {args.top_k}, T=2.0 alpha=0.5, student fwd+bwd + teacher fwd + top-K + KL/CE",
+                       "global_batch": world * args.batch, "seq_len": args.seq_len,
+                       "parallelism": f"dp{world}" if world > 1 else "single"},
+            "step_flops_per_token_algorithmic": f_tok,
+            "step_mfma_frac": (tokens / dt) * f_tok / world / (MFMA_PEAK_TFLOPS * 1e12),
+            "loss": {"total": losses[0], "task": losses[1], "distill": losses[2], "teacher": losses[3]},
+        }
+        if prof is not None:
+            tot_ms = sum(v[0] for v in prof.values())
+            kinds = {k: {"ms_per_step": v[0] / args.steps, "launches_per_step": v[2] / args.steps,
+                         "avg_us": 1e3 * v[0] / max(v[2], 1),
+                         ("tflops" if k.startswith(("gemm", "attn")) else "gbs"):
+                             (v[1] / (v[0] * 1e-3) / (1e12 if k.startswith(("gemm", "attn")) else 1e9)) if v[0] > 0 else 0.0}
+                     for k, v in prof.items() if v[2] > 0}
+            res["kernels"] = kinds
+            res["kernel_ms_per_step_sum"] = tot_ms / args.steps
+            dom = max((k for k in prof if prof[k][2] > 0), key=lambda k: prof[k][0])
+            ms, work, cnt = prof[dom]
+            if dom.startswith(("gemm", "attn")):
+                ach = work / (ms * 1e-3) / 1e12
+                res["roofline"] = {"bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                   "frac": ach / MFMA_PEAK_TFLOPS, "traffic": None,
+                                   "kernel": KERNEL_NAMES.get(dom, dom), "avg_launch_us": 1e3 * ms / cnt,
+                                   "launches_per_step": cnt / args.steps,
+                                   "algorithmic_flops_per_launch_avg": work / cnt}
+            else:
+                ach = work / (ms * 1e-3) / 1e9
+                res["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": ach / HBM_PEAK_GBS, "traffic": None, "kernel": dom,
+                                   "avg_launch_us": 1e3 * ms / cnt, "launches_per_step": cnt / args.steps}
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                res["cpu_baseline"] = cpu_baseline(args.cpu_sample_tokens, min(os.cpu_count() or 1, 16))
+            except Exception as e:  # never lose the GPU line to a host-side problem
+                res["cpu_baseline"] = {"value": None, "error": repr(e)}
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -37,6 +37,15 @@ int sd_abi_version(void);
 int sd_gemm_bf16(const void* A, const void* B, void* C, const void* R, int M, int N, int K, int64_t lda,
                  int64_t ldb, int64_t ldc, int64_t ldr, int trans_a, int trans_b, void* stream);
 
+/* Split-K form for GEMMs with few output tiles and a very long K (lm_head dX: K = vocab): K slices
+ * write fp32 slabs into `workspace`, summed in a fixed order by a second kernel (deterministic).
+ * sd_gemm_splitk_plan returns the number of slices the library would use (1 = no split). */
+int sd_gemm_splitk_plan(int M, int N, int K);
+int64_t sd_gemm_splitk_workspace_bytes(int M, int N, int K);
+int sd_gemm_bf16_splitk(const void* A, const void* B, void* C, const void* R, int M, int N, int K, int64_t lda,
+                        int64_t ldb, int64_t ldc, int64_t ldr, int trans_a, int trans_b, void* workspace,
+                        int64_t workspace_bytes, void* stream);
+
 /* ---- RMSNorm (HF:59-64).  rstd (fp32 [M], nullable in fwd) is saved for backward. */
 int sd_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int M, int H, float eps, void* stream);
 int64_t sd_rmsnorm_bwd_workspace_bytes(int M, int H);
@@ -143,6 +152,15 @@ int sd_qwen3_backward(const sd_qwen3_dims* d, const sd_qwen3_params* p, const sd
                       const int32_t* kv_len, const void* cos_tab, const void* sin_tab, void* acts, int64_t acts_bytes,
                       void* dlogits, void* scratch, int64_t scratch_bytes, int B, int T, int accumulate,
                       sd_stage_cb on_grads_ready, void* cb_user, void* stream);
+
+/* ---- optional live timing (bench.py): HIP events around every launch, on the launch stream.
+ * kinds index the arrays of sd_prof_end; work = algorithmic FLOPs (GEMM, attention) or bytes (others). */
+enum {
+  SD_K_GEMM_NT = 0, SD_K_GEMM_NN, SD_K_GEMM_TN, SD_K_ATTN_FWD, SD_K_ATTN_BWD_DKV, SD_K_ATTN_BWD_DQ, SD_K_LOSS_FWD,
+  SD_K_LOSS_BWD, SD_K_TOPK, SD_K_RMSNORM, SD_K_QKROPE, SD_K_SWIGLU, SD_K_EMBED, SD_K_OPTIM, SD_K_MISC, SD_K_COUNT
+};
+int sd_prof_begin(void);
+int sd_prof_end(double* ms, double* work, int64_t* count, int n_kinds);
 
 #ifdef __cplusplus
 }

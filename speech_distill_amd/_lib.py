@@ -38,6 +38,9 @@ class Params(C.Structure):
                 ("layers_host", C.POINTER(Layer))]
 
 
+KINDS = ["gemm_nt", "gemm_nn", "gemm_tn", "attn_fwd", "attn_bwd_dkv", "attn_bwd_dq", "loss_fwd", "loss_bwd", "topk",
+         "rmsnorm", "qknorm_rope", "swiglu", "embedding", "optim", "misc"]
+
 STAGE_CB = C.CFUNCTYPE(None, C.c_int, C.c_void_p)
 
 _vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
@@ -45,6 +48,9 @@ _vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 PROTOTYPES = {
     "sd_abi_version": (_i, []),
     "sd_gemm_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _i64, _i64, _i, _i, _vp]),
+    "sd_gemm_splitk_plan": (_i, [_i, _i, _i]),
+    "sd_gemm_splitk_workspace_bytes": (_i64, [_i, _i, _i]),
+    "sd_gemm_bf16_splitk": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _i64, _i64, _i, _i, _vp, _i64, _vp]),
     "sd_rmsnorm_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "sd_rmsnorm_bwd_workspace_bytes": (_i64, [_i, _i]),
     "sd_rmsnorm_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _vp]),
@@ -63,6 +69,8 @@ PROTOTYPES = {
     "sd_kdloss_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _i, _vp]),
     "sd_sumsq_bf16": (_i, [_vp, _i64, _vp, _vp]),
     "sd_adamw_bf16": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _vp, _f, _vp]),
+    "sd_prof_begin": (_i, []),
+    "sd_prof_end": (_i, [_vp, _vp, _vp, _i]),
     "sd_qwen3_acts_bytes": (_i64, [C.POINTER(Dims), _i, _i, _i]),
     "sd_qwen3_bwd_scratch_bytes": (_i64, [C.POINTER(Dims), _i, _i]),
     "sd_qwen3_forward": (_i, [C.POINTER(Dims), C.POINTER(Params), _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i, _i, _i, _vp]),

@@ -18,6 +18,7 @@
 //   dV^T = dO^T P, dK^T = Q^T dS.
 #include "sd_common.cuh"
 #include "../../include/sd_hip.h"
+#include "sd_prof.h"
 
 namespace {
 
@@ -437,6 +438,7 @@ extern "C" int sd_attn_fwd(const void* q, const void* k, const void* v, void* o,
   if (head_dim != D) return SD_ERR_UNSUPPORTED;
   if (int e = check_common(B, T, Hq, Hkv, ldq, ldk, ldv, ldo)) return e;
   if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) & 15) return SD_ERR_ALIGN;
+  SdProfScope prof(SD_K_ATTN_FWD, 2.0 * B * Hq * (double)T * T * D, (hipStream_t)stream);  // 2 products, causal half
   hipLaunchKernelGGL(attn_fwd_kernel, dim3((T + 127) / 128, Hq, B), dim3(256), 0, (hipStream_t)stream, (const bf16*)q,
                      (const bf16*)k, (const bf16*)v, (bf16*)o, lse, kv_len, ldq, ldk, ldv, ldo, T, Hq, Hkv, scale);
   SD_CHECK_LAUNCH();
@@ -455,10 +457,14 @@ extern "C" int sd_attn_bwd(const void* q, const void* k, const void* v, const vo
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, st, (const bf16*)d_o,
                      (const bf16*)o, delta, ldo, T, Hq, total);
   SD_CHECK_LAUNCH();
+  {
+  SdProfScope prof(SD_K_ATTN_BWD_DKV, 4.0 * B * Hq * (double)T * T * D, st);  // S, dP, dV, dK
   hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((T + 127) / 128, Hkv, B), dim3(256), 0, st, (const bf16*)q, (const bf16*)k,
                      (const bf16*)v, (const bf16*)d_o, lse, (const float*)delta, (bf16*)dk, (bf16*)dv, kv_len, ldq, ldk,
                      ldv, ldo, lddk, lddv, T, Hq, Hkv, scale);
+  }
   SD_CHECK_LAUNCH();
+  SdProfScope prof2(SD_K_ATTN_BWD_DQ, 3.0 * B * Hq * (double)T * T * D, st);  // S, dP (recomputed), dQ
   hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((T + 127) / 128, Hq, B), dim3(256), 0, st, (const bf16*)q, (const bf16*)k,
                      (const bf16*)v, (const bf16*)d_o, lse, (const float*)delta, (bf16*)dq, kv_len, ldq, ldk, ldv, ldo,
                      lddq, T, Hq, Hkv, scale);

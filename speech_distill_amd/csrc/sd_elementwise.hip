@@ -11,6 +11,7 @@
 // Every kernel moves 16 bytes per lane per access (8 bf16) and reduces with wave shuffles.
 #include "sd_common.cuh"
 #include "../../include/sd_hip.h"
+#include "sd_prof.h"
 
 namespace {
 
@@ -26,7 +27,9 @@ SD_DEV bf16x8 pack8(const float* f) {
 }
 
 // ------------------------------------------------------------------------------------------ RMSNorm
-// One wave per row; the row is read twice (second read is L1/L2 resident).
+// One wave per row, the row held in registers (NCH chunks of 512 columns) between the statistic and
+// the output pass: one HBM read, one write.
+template <int NCH>
 __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ w,
                                                           bf16* __restrict__ y, float* __restrict__ rstd_out, int M,
                                                           int H, float eps) {
@@ -34,82 +37,128 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const bf16* __restrict
   if (row >= M) return;
   const int lane = lane_id();
   const bf16* xr = x + (long)row * H;
+  bf16x8 xv[NCH];
   float ss = 0.f;
-  for (int c = lane * 8; c < H; c += 512) {
-    float f[8];
-    unpack8(*(const bf16x8*)(xr + c), f);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) ss += f[e] * f[e];
+  for (int i = 0; i < NCH; ++i) {
+    const int c = lane * 8 + i * 512;
+    if (c < H) {
+      xv[i] = *(const bf16x8*)(xr + c);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float f = (float)xv[i][e]; ss += f * f; }
+    }
   }
   ss = wave_sum(ss);
   const float rstd = rsqrtf(ss / (float)H + eps);
   if (lane == 0 && rstd_out) rstd_out[row] = rstd;
   bf16* yr = y + (long)row * H;
-  for (int c = lane * 8; c < H; c += 512) {
-    float f[8], g[8];
-    unpack8(*(const bf16x8*)(xr + c), f);
-    unpack8(*(const bf16x8*)(w + c), g);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) f[e] = g[e] * (float)(bf16)(f[e] * rstd);  // HF: weight * hidden.to(bf16)
-    *(bf16x8*)(yr + c) = pack8(f);
+  for (int i = 0; i < NCH; ++i) {
+    const int c = lane * 8 + i * 512;
+    if (c < H) {
+      float f[8], g[8];
+      unpack8(xv[i], f);
+      unpack8(*(const bf16x8*)(w + c), g);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] = g[e] * (float)(bf16)(f[e] * rstd);  // HF: weight * hidden.to(bf16)
+      *(bf16x8*)(yr + c) = pack8(f);
+    }
   }
 }
 
 // dx = rstd * (g - xhat * mean(g*xhat)),  g = dy*w, xhat = x*rstd;  dx (+)= dres.
-// dw partials: block b owns rows [b*rpb, (b+1)*rpb); thread t owns columns 8t.. (H <= 2048*... looped).
+// Gain gradient: every lane owns fixed columns and keeps their sums over this block's rows in
+// registers; the 4 waves are combined through LDS in a fixed order (deterministic), one partial
+// row per block, summed by colsum_reduce_kernel.
+template <int NCH>
 __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ x,
                                                           const bf16* __restrict__ w, const float* __restrict__ rstd,
                                                           const bf16* dres, bf16* dx, float* __restrict__ dw_part,
                                                           int M, int H, int rows_per_block) {
-  extern __shared__ __attribute__((aligned(16))) float dw_s[];  // [H]
-  for (int c = threadIdx.x; c < H; c += 256) dw_s[c] = 0.f;
-  __syncthreads();
+  extern __shared__ __attribute__((aligned(16))) float dw_s[];  // [4][H]
   const int lane = lane_id(), wv = threadIdx.x >> 6;
   const int r0 = blockIdx.x * rows_per_block;
   const int r1 = min(M, r0 + rows_per_block);
+  float acc[NCH][8];
+  float wf[NCH][8];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = lane * 8 + i * 512;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[i][e] = 0.f;
+    if (c < H) unpack8(*(const bf16x8*)(w + c), wf[i]);
+  }
   for (int row = r0 + wv; row < r1; row += 4) {
     const bf16* xr = x + (long)row * H;
     const bf16* dyr = dy + (long)row * H;
     const float rs = rstd[row];
+    bf16x8 xv[NCH], dv[NCH];
     float dot = 0.f;
-    for (int c = lane * 8; c < H; c += 512) {
-      float xf[8], df[8], wf[8];
-      unpack8(*(const bf16x8*)(xr + c), xf);
-      unpack8(*(const bf16x8*)(dyr + c), df);
-      unpack8(*(const bf16x8*)(w + c), wf);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) dot += df[e] * wf[e] * xf[e] * rs;
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane * 8 + i * 512;
+      if (c < H) {
+        xv[i] = *(const bf16x8*)(xr + c);
+        dv[i] = *(const bf16x8*)(dyr + c);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dot += (float)dv[i][e] * wf[i][e] * (float)xv[i][e] * rs;
+      }
     }
     dot = wave_sum(dot) / (float)H;
-    for (int c = lane * 8; c < H; c += 512) {
-      float xf[8], df[8], wf[8], o[8];
-      unpack8(*(const bf16x8*)(xr + c), xf);
-      unpack8(*(const bf16x8*)(dyr + c), df);
-      unpack8(*(const bf16x8*)(w + c), wf);
-      if (dres) unpack8(*(const bf16x8*)(dres + (long)row * H + c), o);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float xh = xf[e] * rs;
-        const float v = rs * (df[e] * wf[e] - xh * dot);
-        o[e] = dres ? o[e] + v : v;
-        atomicAdd(&dw_s[c + e], df[e] * xh);  // LDS atomic: 4 waves share the column sums
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane * 8 + i * 512;
+      if (c < H) {
+        float o[8];
+        if (dres) unpack8(*(const bf16x8*)(dres + (long)row * H + c), o);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float xh = (float)xv[i][e] * rs, d = (float)dv[i][e];
+          const float v = rs * (d * wf[i][e] - xh * dot);
+          o[e] = dres ? o[e] + v : v;
+          acc[i][e] += d * xh;
+        }
+        *(bf16x8*)(dx + (long)row * H + c) = pack8(o);
       }
-      *(bf16x8*)(dx + (long)row * H + c) = pack8(o);
     }
   }
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = lane * 8 + i * 512;
+    if (c < H)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dw_s[wv * H + c + e] = acc[i][e];
+  }
   __syncthreads();
-  for (int c = threadIdx.x; c < H; c += 256) dw_part[(long)blockIdx.x * H + c] = dw_s[c];
+  for (int c = threadIdx.x; c < H; c += 256)
+    dw_part[(long)blockIdx.x * H + c] = (dw_s[c] + dw_s[H + c]) + (dw_s[2 * H + c] + dw_s[3 * H + c]);
 }
 
-// out[c] (bf16) = (accumulate ? out[c] : 0) + sum_b part[b][c]
-__global__ void colsum_reduce_kernel(const float* __restrict__ part, bf16* out, int nb, int H, int stride,
-                                     int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= H) return;
+// out[c] (bf16) = (accumulate ? out[c] : 0) + sum_b part[b*stride + c].  Block = 32 columns x 8 row
+// groups; every thread sums its rows with 8 independent loads in flight, then a fixed-order LDS reduce.
+__global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* __restrict__ part, bf16* out, int nb, int H,
+                                                            int stride, int accumulate) {
+  __shared__ float red[8][32];
+  const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
   float s = 0.f;
-  for (int b = 0; b < nb; ++b) s += part[(long)b * stride + c];
-  if (accumulate) s += (float)out[c];
-  out[c] = (bf16)s;
+  if (c < H) {
+    int b = rg;
+    for (; b + 56 < nb; b += 64) {
+      float t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = part[(long)(b + 8 * u) * stride + c];
+      s += ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+    }
+    for (; b < nb; b += 8) s += part[(long)b * stride + c];
+  }
+  red[rg][cl] = s;
+  __syncthreads();
+  if (rg == 0 && c < H) {
+    float t = ((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl])) + ((red[4][cl] + red[5][cl]) + (red[6][cl] + red[7][cl]));
+    if (accumulate) t += (float)out[c];
+    out[c] = (bf16)t;
+  }
 }
 
 // ---------------------------------------------------------------------------- q/k norm + RoPE (d=128)
@@ -157,9 +206,7 @@ __global__ __launch_bounds__(256) void qknorm_rope_bwd_kernel(const bf16* __rest
                                                               const bf16* __restrict__ cosb, const bf16* __restrict__ sinb,
                                                               bf16* __restrict__ dqkv, float* __restrict__ dw_part, int M,
                                                               int T, int Hq, int Hkv, float eps, int items_per_block) {
-  __shared__ float dw_s[256];
-  dw_s[threadIdx.x] = 0.f;
-  __syncthreads();
+  __shared__ float dw_s[16][256];  // [wave*4+sub][q gain 0..127 | k gain 128..255]
   const int lane = lane_id();
   const int sub = lane >> 4, j = lane & 15;
   const int nh = Hq + Hkv;
@@ -205,13 +252,17 @@ __global__ __launch_bounds__(256) void qknorm_rope_bwd_kernel(const bf16* __rest
     }
     if (ok) *(bf16x8*)(dqkv + (long)m * (Hq + 2 * Hkv) * 128 + hh * 128 + j * 8) = pack8(o);
   }
+  const int slot = (threadIdx.x >> 6) * 4 + sub;
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-    atomicAdd(&dw_s[j * 8 + e], accw[e]);
-    atomicAdd(&dw_s[128 + j * 8 + e], acck[e]);
+    dw_s[slot][j * 8 + e] = accw[e];
+    dw_s[slot][128 + j * 8 + e] = acck[e];
   }
   __syncthreads();
-  dw_part[(long)blockIdx.x * 256 + threadIdx.x] = dw_s[threadIdx.x];
+  float t = 0.f;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) t += dw_s[q][threadIdx.x];
+  dw_part[(long)blockIdx.x * 256 + threadIdx.x] = t;
 }
 
 // ------------------------------------------------------------------------------------------- SwiGLU
@@ -294,8 +345,13 @@ __global__ __launch_bounds__(256) void embedding_bwd_kernel(const int64_t* __res
 
 extern "C" int sd_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int M, int H, float eps, void* stream) {
   if (M <= 0 || (H & 7)) return SD_ERR_SHAPE;
-  hipLaunchKernelGGL(rmsnorm_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, ST, (const bf16*)x, (const bf16*)w, (bf16*)y,
-                     rstd, M, H, eps);
+  if (H > 4096) return SD_ERR_UNSUPPORTED;
+  SdProfScope prof(SD_K_RMSNORM, 4.0 * M * H, ST);
+#define SD_RMS_FWD(N) hipLaunchKernelGGL(rmsnorm_fwd_kernel<N>, dim3((M + 3) / 4), dim3(256), 0, ST, (const bf16*)x, \
+                                         (const bf16*)w, (bf16*)y, rstd, M, H, eps)
+  const int nch = (H + 511) / 512;
+  if (nch <= 1) SD_RMS_FWD(1); else if (nch == 2) SD_RMS_FWD(2); else if (nch <= 4) SD_RMS_FWD(4); else SD_RMS_FWD(8);
+#undef SD_RMS_FWD
   SD_CHECK_LAUNCH();
   return 0;
 }
@@ -307,14 +363,20 @@ extern "C" int64_t sd_rmsnorm_bwd_workspace_bytes(int M, int H) {
 
 extern "C" int sd_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, const void* dres, void* dx,
                               void* dw, int accumulate_dw, void* workspace, int M, int H, void* stream) {
-  if (M <= 0 || (H & 7) || H > 16384) return SD_ERR_SHAPE;
+  if (M <= 0 || (H & 7)) return SD_ERR_SHAPE;
+  if (H > 4096) return SD_ERR_UNSUPPORTED;
   int nb = (M + 7) / 8 < 256 ? (M + 7) / 8 : 256;
   const int rpb = (M + nb - 1) / nb;
   nb = (M + rpb - 1) / rpb;
-  hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3(nb), dim3(256), H * 4, ST, (const bf16*)dy, (const bf16*)x, (const bf16*)w,
-                     rstd, (const bf16*)dres, (bf16*)dx, (float*)workspace, M, H, rpb);
+  SdProfScope prof(SD_K_RMSNORM, (dres ? 8.0 : 6.0) * M * H, ST);
+#define SD_RMS_BWD(N) hipLaunchKernelGGL(rmsnorm_bwd_kernel<N>, dim3(nb), dim3(256), 4 * H * 4, ST, (const bf16*)dy, \
+                                         (const bf16*)x, (const bf16*)w, rstd, (const bf16*)dres, (bf16*)dx,       \
+                                         (float*)workspace, M, H, rpb)
+  const int nch = (H + 511) / 512;
+  if (nch <= 1) SD_RMS_BWD(1); else if (nch == 2) SD_RMS_BWD(2); else if (nch <= 4) SD_RMS_BWD(4); else SD_RMS_BWD(8);
+#undef SD_RMS_BWD
   SD_CHECK_LAUNCH();
-  hipLaunchKernelGGL(colsum_reduce_kernel, dim3((H + 255) / 256), dim3(256), 0, ST, (const float*)workspace, (bf16*)dw,
+  hipLaunchKernelGGL(colsum_reduce_kernel, dim3((H + 31) / 32), dim3(256), 0, ST, (const float*)workspace, (bf16*)dw,
                      nb, H, H, accumulate_dw);
   SD_CHECK_LAUNCH();
   return 0;
@@ -325,6 +387,7 @@ extern "C" int sd_qknorm_rope_fwd(const void* qkv, const void* q_gain, const voi
                                   void* stream) {
   if (M <= 0 || T <= 0 || (M % T)) return SD_ERR_SHAPE;
   const long items = (long)M * (Hq + Hkv);
+  SdProfScope prof(SD_K_QKROPE, 4.0 * items * 128, ST);
   hipLaunchKernelGGL(qknorm_rope_fwd_kernel, dim3((unsigned)((items + 15) / 16)), dim3(256), 0, ST, (const bf16*)qkv,
                      (const bf16*)q_gain, (const bf16*)k_gain, (const bf16*)cos_tab, (const bf16*)sin_tab, (bf16*)qk_out,
                      M, T, Hq, Hkv, eps);
@@ -351,15 +414,16 @@ extern "C" int sd_qknorm_rope_bwd(const void* dqk, const void* qkv, const void* 
   if (M <= 0 || T <= 0 || (M % T)) return SD_ERR_SHAPE;
   int ipb;
   const int nb = qk_bwd_blocks((long)M * (Hq + Hkv), &ipb);
+  SdProfScope prof(SD_K_QKROPE, 6.0 * M * (Hq + Hkv) * 128, ST);
   hipLaunchKernelGGL(qknorm_rope_bwd_kernel, dim3(nb), dim3(256), 0, ST, (const bf16*)dqk, (const bf16*)qkv,
                      (const bf16*)q_gain, (const bf16*)k_gain, (const bf16*)cos_tab, (const bf16*)sin_tab, (bf16*)dqkv,
                      (float*)workspace, M, T, Hq, Hkv, eps, ipb);
   SD_CHECK_LAUNCH();
   // partial layout [nb][256]: columns 0..127 -> q gain, 128..255 -> k gain
-  hipLaunchKernelGGL(colsum_reduce_kernel, dim3(1), dim3(128), 0, ST, (const float*)workspace, (bf16*)dq_gain, nb, 128,
+  hipLaunchKernelGGL(colsum_reduce_kernel, dim3(4), dim3(256), 0, ST, (const float*)workspace, (bf16*)dq_gain, nb, 128,
                      256, accumulate_dw);
   SD_CHECK_LAUNCH();
-  hipLaunchKernelGGL(colsum_reduce_kernel, dim3(1), dim3(128), 0, ST, (const float*)workspace + 128, (bf16*)dk_gain,
+  hipLaunchKernelGGL(colsum_reduce_kernel, dim3(4), dim3(256), 0, ST, (const float*)workspace + 128, (bf16*)dk_gain,
                      nb, 128, 256, accumulate_dw);
   SD_CHECK_LAUNCH();
   return 0;
@@ -369,6 +433,7 @@ extern "C" int sd_swiglu_fwd(const void* gate_up, void* act, int M, int I, void*
   if (M <= 0 || (I & 7)) return SD_ERR_SHAPE;
   const long n8 = (long)M * I / 8;
   const int nb = (int)((n8 + 255) / 256 < 4096 ? (n8 + 255) / 256 : 4096);
+  SdProfScope prof(SD_K_SWIGLU, 6.0 * M * I, ST);
   hipLaunchKernelGGL(swiglu_fwd_kernel, dim3(nb), dim3(256), 0, ST, (const bf16*)gate_up, (bf16*)act, n8, I);
   SD_CHECK_LAUNCH();
   return 0;
@@ -378,6 +443,7 @@ extern "C" int sd_swiglu_bwd(const void* dact, const void* gate_up, void* dgate_
   if (M <= 0 || (I & 7)) return SD_ERR_SHAPE;
   const long n8 = (long)M * I / 8;
   const int nb = (int)((n8 + 255) / 256 < 4096 ? (n8 + 255) / 256 : 4096);
+  SdProfScope prof(SD_K_SWIGLU, 10.0 * M * I, ST);
   hipLaunchKernelGGL(swiglu_bwd_kernel, dim3(nb), dim3(256), 0, ST, (const bf16*)dact, (const bf16*)gate_up,
                      (bf16*)dgate_up, n8, I);
   SD_CHECK_LAUNCH();
@@ -386,6 +452,7 @@ extern "C" int sd_swiglu_bwd(const void* dact, const void* gate_up, void* dgate_
 
 extern "C" int sd_embedding_fwd(const int64_t* ids, const void* E, void* x, int M, int H, int V, void* stream) {
   if (M <= 0 || (H & 7)) return SD_ERR_SHAPE;
+  SdProfScope prof(SD_K_EMBED, 4.0 * M * H, ST);
   hipLaunchKernelGGL(embedding_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, ST, ids, (const bf16*)E, (bf16*)x, M, H, V);
   SD_CHECK_LAUNCH();
   return 0;
@@ -393,6 +460,7 @@ extern "C" int sd_embedding_fwd(const int64_t* ids, const void* E, void* x, int 
 
 extern "C" int sd_embedding_bwd(const int64_t* ids, const void* dx, void* dE, int M, int H, int V, void* stream) {
   if (M <= 0 || (H & 7)) return SD_ERR_SHAPE;
+  SdProfScope prof(SD_K_EMBED, 6.0 * M * H, ST);
   hipLaunchKernelGGL(embedding_bwd_kernel, dim3(M), dim3(256), 0, ST, ids, (const bf16*)dx, (bf16*)dE, M, H, V);
   SD_CHECK_LAUNCH();
   return 0;

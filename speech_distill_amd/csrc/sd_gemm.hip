@@ -8,52 +8,60 @@
 //   NN  (ta=0,tb=1)  dX[M,K] = dY[M,N]  . W[N,K]        (B stored [k][n])
 //   TN  (ta=1,tb=1)  dW[N,K] = dY[M,N]^T . X[M,K]       (A stored [k][m], B stored [k][n])
 //
-// Tile 128x128x64, 256 threads = 4 waves (2x2), each wave 64x64 = 4x4 v_mfma_f32_16x16x32_bf16.
-// Operand tiles go HBM -> LDS by 16-byte LDS-DMA (global_load_lds_dwordx4), double buffered; the
-// LDS image is lane-linear, so the bank-conflict swizzle is applied to the per-lane SOURCE address
-// and undone on the fragment read.  K-contiguous operands are read with ds_read_b128, operands
-// whose contraction index is the slow one with ds_read_b64_tr_b16 (hardware transpose).  The
-// accumulator is produced transposed (mfma(Bfrag, Afrag)) so a lane owns 4 consecutive n; it is
-// staged through LDS as fp32 and written out in full 16-byte row pieces with the epilogue fused.
+// Tile BM x 128 x 64 with BM = 128 or 64 (picked so that the grid fills 256 CUs), 256 threads =
+// 4 waves (2x2), each wave (BM/2) x 64 of v_mfma_f32_16x16x32_bf16.  Operand tiles go HBM -> LDS by
+// 16-byte LDS-DMA (global_load_lds_dwordx4), double buffered; the LDS image is lane-linear, so the
+// bank-conflict swizzle is applied to the per-lane SOURCE address and undone on the fragment read.
+// K-contiguous operands are read with ds_read_b128, operands whose contraction index is the slow
+// one with ds_read_b64_tr_b16 (hardware transpose).  The accumulator is produced transposed
+// (mfma(Bfrag, Afrag)) so a lane owns 4 consecutive n; it is staged through LDS as fp32 and written
+// out in full 16-byte row pieces with the epilogue fused.  Optional split-K (very long K, few
+// tiles): each K slice writes an fp32 slab, a second kernel sums the slabs in a fixed order.
 #include "sd_common.cuh"
 #include "../../include/sd_hip.h"
+#include "sd_prof.h"
 
 extern "C" __device__ __attribute__((aligned(256))) unsigned char sd_zero_page[1024] = {0};
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand per stage
+constexpr int BN = 128, BK = 64;
 
-SD_DEV int swz_t(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
+// XOR applied to the 32-byte chunk index of a transposed-operand tile row k ([64 k][ROWS] image)
+template <int ROWS> SD_DEV int swz_t(int k) {
+  if constexpr (ROWS == 128) return (k & 3) | (((k >> 3) & 1) << 2);  // 8 chunks / 256-byte row
+  else return ((k >> 1) & 1) | (((k >> 3) & 1) << 1);                 // 4 chunks / 128-byte row, 2 rows per bank row
+}
 
-// Stage one 128 x 64 operand tile into LDS.  TX=false: operand stored [rows][K] (K contiguous).
+// Stage one ROWS x 64 operand tile into LDS.  TX=false: operand stored [rows][K] (K contiguous).
 // TX=true: operand stored [K][rows] (rows contiguous).
-template <bool TX>
-SD_DEV void stage_tile(const bf16* __restrict__ g, long ld, int row0, int k0, int row_lim, int K,
-                       char* lds_tile, int w, int lane) {
+template <bool TX, int ROWS>
+SD_DEV void stage_tile(const bf16* __restrict__ g, long ld, int row0, int k0, int row_lim, int k_lim, char* lds_tile,
+                       int w, int lane) {
+  constexpr int NI = ROWS / 32;  // 1 KiB wave-issues per wave
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int p = (w * 4 + i) * 64 + lane;
+  for (int i = 0; i < NI; ++i) {
+    const int p = (w * NI + i) * 64 + lane;
     const bf16* src;
     if constexpr (!TX) {
       const int r = p >> 3, s = p & 7, c = s ^ (r & 7);
       const int gr = row0 + r, gk = k0 + c * 8;
       src = g + (long)gr * ld + gk;
-      if (gr >= row_lim || gk >= K) src = (const bf16*)(sd_zero_page + lane * 16);
+      if (gr >= row_lim || gk >= k_lim) src = (const bf16*)(sd_zero_page + lane * 16);
     } else {
-      const int k = p >> 4, u = p & 15;
-      const int ch = (u >> 1) ^ swz_t(k);
+      constexpr int UPR = ROWS / 8;  // 16-byte units per k-row
+      const int k = p / UPR, u = p % UPR;
+      const int ch = (u >> 1) ^ swz_t<ROWS>(k);
       const int gc = row0 + ch * 16 + (u & 1) * 8, gk = k0 + k;
       src = g + (long)gk * ld + gc;
-      if (gk >= K || gc >= row_lim) src = (const bf16*)(sd_zero_page + lane * 16);
+      if (gk >= k_lim || gc >= row_lim) src = (const bf16*)(sd_zero_page + lane * 16);
     }
-    glds16(src, lds_tile + (w * 4 + i) * 1024);
+    glds16(src, lds_tile + (w * NI + i) * 1024);
   }
 }
 
 // Fragment of 16 rows x 32 k for v_mfma_f32_16x16x32_bf16: lane l holds row (l&15), k = 8(l>>4)+j.
-template <bool TX>
+template <bool TX, int ROWS>
 SD_DEV bf16x8 load_frag(const char* lds_tile, int row16_base, int kk, int lane) {
   if constexpr (!TX) {
     const int r = row16_base + (lane & 15);
@@ -64,17 +72,23 @@ SD_DEV bf16x8 load_frag(const char* lds_tile, int row16_base, int kk, int lane) 
     const int ch = row16_base >> 4;
     const int k0 = kk * 32 + 8 * g + q;
     const int k1 = k0 + 4;
-    bf16x4 lo = lds_tr16(lds_tile + k0 * 256 + ((ch ^ swz_t(k0)) << 5) + 8 * pp);
-    bf16x4 hi = lds_tr16(lds_tile + k1 * 256 + ((ch ^ swz_t(k1)) << 5) + 8 * pp);
+    bf16x4 lo = lds_tr16(lds_tile + k0 * (ROWS * 2) + ((ch ^ swz_t<ROWS>(k0)) << 5) + 8 * pp);
+    bf16x4 hi = lds_tr16(lds_tile + k1 * (ROWS * 2) + ((ch ^ swz_t<ROWS>(k1)) << 5) + 8 * pp);
     return cat8(lo, hi);
   }
 }
 
-template <bool TA, bool TB, bool HAS_R>
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(
-    const bf16* __restrict__ A, const bf16* __restrict__ B, bf16* C, const bf16* R,
-    int M, int N, int K, long lda, long ldb, long ldc, long ldr, int tiles_m, int tiles_n) {
-  __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];  // 2 stages x (A,B) = 64 KiB
+// EPI: 0 = bf16 out, 1 = bf16 out + residual, 2 = fp32 slab out (split-K)
+template <int BM, bool TA, bool TB, int EPI>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B, bf16* C,
+                                                        const bf16* R, float* __restrict__ slabs, int M, int N, int K,
+                                                        long lda, long ldb, long ldc, long ldr, int tiles_m, int tiles_n,
+                                                        int k_tiles_per_split) {
+  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
+  constexpr int MT = BM / 32;  // 16-row MFMA tiles per wave along M
+  constexpr int EPI_BYTES = BM * BN * 4;
+  constexpr int SMEM = (2 * STAGE > EPI_BYTES) ? 2 * STAGE : EPI_BYTES;
+  __shared__ __attribute__((aligned(16))) char smem[SMEM];
   const int lane = lane_id();
   const int w = wave_id_uniform();
   const int wm = w >> 1, wn = w & 1;
@@ -82,44 +96,49 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(
   const int tm = tile % tiles_m, tn = tile / tiles_m;
   const int m0 = tm * BM, n0 = tn * BN;
 
-  f32x4 acc[4][4];
+  f32x4 acc[MT][4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = (K + BK - 1) / BK;
-  stage_tile<TA>(A, lda, m0, 0, M, K, smem, w, lane);
-  stage_tile<TB>(B, ldb, n0, 0, N, K, smem + TILE_BYTES, w, lane);
+  const int kt_all = (K + BK - 1) / BK;
+  const int kt0 = blockIdx.y * k_tiles_per_split;
+  const int kt1 = min(kt_all, kt0 + k_tiles_per_split);
+  const int nk = kt1 - kt0;
+  if (nk > 0) {
+    stage_tile<TA, BM>(A, lda, m0, kt0 * BK, M, K, smem, w, lane);
+    stage_tile<TB, BN>(B, ldb, n0, kt0 * BK, N, K, smem + A_BYTES, w, lane);
+  }
   __syncthreads();
 
   for (int t = 0; t < nk; ++t) {
-    char* cur = smem + (t & 1) * 2 * TILE_BYTES;
+    char* cur = smem + (t & 1) * STAGE;
     if (t + 1 < nk) {
-      char* nxt = smem + ((t + 1) & 1) * 2 * TILE_BYTES;
-      stage_tile<TA>(A, lda, m0, (t + 1) * BK, M, K, nxt, w, lane);
-      stage_tile<TB>(B, ldb, n0, (t + 1) * BK, N, K, nxt + TILE_BYTES, w, lane);
+      char* nxt = smem + ((t + 1) & 1) * STAGE;
+      stage_tile<TA, BM>(A, lda, m0, (kt0 + t + 1) * BK, M, K, nxt, w, lane);
+      stage_tile<TB, BN>(B, ldb, n0, (kt0 + t + 1) * BK, N, K, nxt + A_BYTES, w, lane);
     }
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      bf16x8 af[4], bfr[4];
+      bf16x8 af[MT], bfr[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) af[i] = load_frag<TA>(cur, wm * 64 + i * 16, kk, lane);
+      for (int i = 0; i < MT; ++i) af[i] = load_frag<TA, BM>(cur, wm * (BM / 2) + i * 16, kk, lane);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) bfr[j] = load_frag<TB>(cur + TILE_BYTES, wn * 64 + j * 16, kk, lane);
+      for (int j = 0; j < 4; ++j) bfr[j] = load_frag<TB, BN>(cur + A_BYTES, wn * 64 + j * 16, kk, lane);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(bfr[j], af[i], acc[i][j]);  // D[n][m]: lane owns 4 consecutive n
     }
     __syncthreads();  // waits the LDS-DMA of tile t+1 (vmcnt(0)) and fences the reads of tile t
   }
 
-  // Epilogue: fp32 tile -> LDS (XOR-swizzled 16-byte chunks), then coalesced bf16 rows out.
-  float* cs = (float*)smem;  // [128][128] fp32 = 64 KiB
+  // Epilogue: fp32 tile -> LDS (XOR-swizzled 16-byte chunks), then coalesced rows out.
+  float* cs = (float*)smem;  // [BM][128] fp32
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = wm * 64 + i * 16 + (lane & 15);
+  for (int i = 0; i < MT; ++i) {
+    const int m = wm * (BM / 2) + i * 16 + (lane & 15);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int cidx = wn * 16 + j * 4 + (lane >> 4);
@@ -128,55 +147,139 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(
   }
   __syncthreads();
 #pragma unroll
-  for (int it = 0; it < 8; ++it) {
+  for (int it = 0; it < BM / 16; ++it) {
     const int q = it * 256 + threadIdx.x;
     const int m = q >> 4, oc = q & 15;
     const int gm = m0 + m, gn = n0 + oc * 8;
     if (gm < M && gn < N) {
       f32x4 lo = *(const f32x4*)(cs + m * 128 + (((2 * oc) ^ (m & 15)) << 2));
       f32x4 hi = *(const f32x4*)(cs + m * 128 + (((2 * oc + 1) ^ (m & 15)) << 2));
-      float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-      if constexpr (HAS_R) {
-        bf16x8 r = *(const bf16x8*)(R + (long)gm * ldr + gn);
+      if constexpr (EPI == 2) {
+        float* dst = slabs + ((long)blockIdx.y * M + gm) * N + gn;
+        *(f32x4*)dst = lo;
+        *(f32x4*)(dst + 4) = hi;
+      } else {
+        float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        if constexpr (EPI == 1) {
+          bf16x8 r = *(const bf16x8*)(R + (long)gm * ldr + gn);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += (float)r[e];
+          for (int e = 0; e < 8; ++e) v[e] += (float)r[e];
+        }
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
+        *(bf16x8*)(C + (long)gm * ldc + gn) = o;
       }
-      bf16x8 o;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
-      *(bf16x8*)(C + (long)gm * ldc + gn) = o;
     }
   }
 }
 
-template <bool TA, bool TB>
-int launch(const void* A, const void* B, void* C, const void* R, int M, int N, int K, long lda, long ldb, long ldc,
-           long ldr, hipStream_t st) {
+// C = sum_s slab[s] (+ R), fixed order
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slabs, bf16* C, const bf16* R, int M,
+                                                            int N, long ldc, long ldr, int splits) {
+  const long n8 = (long)M * N / 8;
+  const int row8 = N / 8;
+  for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < n8; q += (long)gridDim.x * 256) {
+    const long m = q / row8;
+    const int n = (int)(q % row8) * 8;
+    float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int s = 0; s < splits; ++s) {
+      const float* p = slabs + ((long)s * M + m) * N + n;
+      f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
+      v[0] += a[0]; v[1] += a[1]; v[2] += a[2]; v[3] += a[3]; v[4] += b[0]; v[5] += b[1]; v[6] += b[2]; v[7] += b[3];
+    }
+    if (R) {
+      bf16x8 r = *(const bf16x8*)(R + m * ldr + n);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += (float)r[e];
+    }
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
+    *(bf16x8*)(C + m * ldc + n) = o;
+  }
+}
+
+template <int BM, bool TA, bool TB>
+int launch(const void* A, const void* B, void* C, const void* R, float* slabs, int splits, int M, int N, int K, long lda,
+           long ldb, long ldc, long ldr, hipStream_t st) {
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
-  dim3 grid(tiles_m * tiles_n), block(256);
-  if (R)
-    hipLaunchKernelGGL((gemm_bf16_kernel<TA, TB, true>), grid, block, 0, st, (const bf16*)A, (const bf16*)B, (bf16*)C,
-                       (const bf16*)R, M, N, K, lda, ldb, ldc, ldr, tiles_m, tiles_n);
-  else
-    hipLaunchKernelGGL((gemm_bf16_kernel<TA, TB, false>), grid, block, 0, st, (const bf16*)A, (const bf16*)B, (bf16*)C,
-                       (const bf16*)nullptr, M, N, K, lda, ldb, ldc, ldr, tiles_m, tiles_n);
+  const int kt_all = (K + BK - 1) / BK;
+  const int per = (kt_all + splits - 1) / splits;
+  dim3 grid(tiles_m * tiles_n, splits), block(256);
+#define SD_GEMM_GO(EPI)                                                                                              \
+  hipLaunchKernelGGL((gemm_bf16_kernel<BM, TA, TB, EPI>), grid, block, 0, st, (const bf16*)A, (const bf16*)B, (bf16*)C, \
+                     (const bf16*)R, slabs, M, N, K, lda, ldb, ldc, ldr, tiles_m, tiles_n, per)
+  if (splits > 1) SD_GEMM_GO(2);
+  else if (R) SD_GEMM_GO(1);
+  else SD_GEMM_GO(0);
+#undef SD_GEMM_GO
   SD_CHECK_LAUNCH();
+  if (splits > 1) {
+    const long n8 = (long)M * N / 8;
+    const int nb = (int)((n8 + 255) / 256 < 2048 ? (n8 + 255) / 256 : 2048);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(nb), dim3(256), 0, st, (const float*)slabs, (bf16*)C, (const bf16*)R, M,
+                       N, ldc, ldr, splits);
+    SD_CHECK_LAUNCH();
+  }
   return 0;
 }
 
-}  // namespace
-
-extern "C" int sd_gemm_bf16(const void* A, const void* B, void* C, const void* R, int M, int N, int K, int64_t lda,
-                            int64_t ldb, int64_t ldc, int64_t ldr, int trans_a, int trans_b, void* stream) {
+int check_args(const void* A, const void* B, const void* C, const void* R, int M, int N, int K, int64_t lda, int64_t ldb,
+               int64_t ldc, int64_t ldr, int trans_a, int trans_b) {
   if (M <= 0 || N <= 0 || K <= 0) return SD_ERR_SHAPE;
   if ((lda | ldb | ldc | (R ? ldr : 0)) & 7) return SD_ERR_ALIGN;
   if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C | (uintptr_t)R) & 15) return SD_ERR_ALIGN;
   if (N & 7) return SD_ERR_ALIGN;
   if ((!trans_a || !trans_b) && (K & 7)) return SD_ERR_ALIGN;
   if (trans_a && (M & 7)) return SD_ERR_ALIGN;
-  hipStream_t st = (hipStream_t)stream;
-  if (!trans_a && !trans_b) return launch<false, false>(A, B, C, R, M, N, K, lda, ldb, ldc, ldr, st);
-  if (!trans_a && trans_b) return launch<false, true>(A, B, C, R, M, N, K, lda, ldb, ldc, ldr, st);
-  if (trans_a && trans_b) return launch<true, true>(A, B, C, R, M, N, K, lda, ldb, ldc, ldr, st);
-  return launch<true, false>(A, B, C, R, M, N, K, lda, ldb, ldc, ldr, st);
+  return 0;
+}
+
+int dispatch(const void* A, const void* B, void* C, const void* R, float* slabs, int splits, int M, int N, int K,
+             long lda, long ldb, long ldc, long ldr, int ta, int tb, hipStream_t st) {
+  // 128-row tiles unless they leave the 256 CUs (2 resident blocks each) under-filled
+  const long tiles128 = (long)((M + 127) / 128) * ((N + BN - 1) / BN) * splits;
+  const bool small = tiles128 < 448;
+  SdProfScope prof(ta ? SD_K_GEMM_TN : (tb ? SD_K_GEMM_NN : SD_K_GEMM_NT), 2.0 * M * N * K, st);
+#define SD_GO(BM_, TA_, TB_) return launch<BM_, TA_, TB_>(A, B, C, R, slabs, splits, M, N, K, lda, ldb, ldc, ldr, st)
+  if (!ta && !tb) { if (small) SD_GO(64, false, false); SD_GO(128, false, false); }
+  if (!ta && tb) { if (small) SD_GO(64, false, true); SD_GO(128, false, true); }
+  if (ta && tb) { if (small) SD_GO(64, true, true); SD_GO(128, true, true); }
+  if (small) SD_GO(64, true, false);
+  SD_GO(128, true, false);
+#undef SD_GO
+}
+
+}  // namespace
+
+extern "C" int sd_gemm_bf16(const void* A, const void* B, void* C, const void* R, int M, int N, int K, int64_t lda,
+                            int64_t ldb, int64_t ldc, int64_t ldr, int trans_a, int trans_b, void* stream) {
+  if (int e = check_args(A, B, C, R, M, N, K, lda, ldb, ldc, ldr, trans_a, trans_b)) return e;
+  return dispatch(A, B, C, R, nullptr, 1, M, N, K, lda, ldb, ldc, ldr, trans_a, trans_b, (hipStream_t)stream);
+}
+
+extern "C" int sd_gemm_splitk_plan(int M, int N, int K) {
+  const long tiles = (long)((M + 63) / 64) * ((N + BN - 1) / BN);
+  const int kt = (K + BK - 1) / BK;
+  if (tiles >= 512 || kt < 64) return 1;
+  int s = (int)((768 + tiles - 1) / tiles);
+  if (s > 8) s = 8;
+  if (s > kt / 16) s = kt / 16;
+  return s < 1 ? 1 : s;
+}
+
+extern "C" int64_t sd_gemm_splitk_workspace_bytes(int M, int N, int K) {
+  const int s = sd_gemm_splitk_plan(M, N, K);
+  return s > 1 ? (int64_t)s * M * N * 4 : 0;
+}
+
+extern "C" int sd_gemm_bf16_splitk(const void* A, const void* B, void* C, const void* R, int M, int N, int K, int64_t lda,
+                                   int64_t ldb, int64_t ldc, int64_t ldr, int trans_a, int trans_b, void* workspace,
+                                   int64_t workspace_bytes, void* stream) {
+  if (int e = check_args(A, B, C, R, M, N, K, lda, ldb, ldc, ldr, trans_a, trans_b)) return e;
+  int s = sd_gemm_splitk_plan(M, N, K);
+  if (s > 1 && (workspace == nullptr || workspace_bytes < (int64_t)s * M * N * 4)) s = 1;
+  if (s > 1 && ((uintptr_t)workspace & 15)) return SD_ERR_ALIGN;
+  return dispatch(A, B, C, R, (float*)workspace, s, M, N, K, lda, ldb, ldc, ldr, trans_a, trans_b, (hipStream_t)stream);
 }

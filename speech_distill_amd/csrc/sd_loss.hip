@@ -16,6 +16,7 @@
 // partials + a fixed-order final reduce); no float atomics.
 #include "sd_common.cuh"
 #include "../../include/sd_hip.h"
+#include "sd_prof.h"
 
 namespace {
 
@@ -278,6 +279,7 @@ template <typename T>
 int run_fwd(const void* S, const void* Tl, const void* topv, const void* topi, const int64_t* labels, const uint8_t* mask,
             void* stats, float* out, int B, int Tlen, int V, int K, float temperature, float alpha, hipStream_t st) {
   const int rows = B * Tlen;
+  SdProfScope prof(SD_K_LOSS_FWD, (double)rows * V * sizeof(T) * (Tl ? 2 : 1), st);
   hipLaunchKernelGGL((kd_fwd_kernel<T>), dim3(rows), dim3(NT), 0, st, (const T*)S, (const T*)Tl, (const _Float16*)topv,
                      (const int32_t*)topi, labels, mask, (RowStats*)stats, rows, Tlen, V, K, temperature);
   SD_CHECK_LAUNCH();
@@ -292,6 +294,7 @@ int run_bwd(const void* S, const void* Tl, const void* topv, const void* topi, c
             const float* out, const float* go, void* G, int B, int Tlen, int V, int K, float temperature, float alpha,
             hipStream_t st) {
   const int rows = B * Tlen;
+  SdProfScope prof(SD_K_LOSS_BWD, (double)rows * V * sizeof(T) * (Tl ? 3 : 2), st);
   hipLaunchKernelGGL((kd_bwd_kernel<T>), dim3(rows), dim3(NT), 0, st, (const T*)S, (const T*)Tl, (const _Float16*)topv,
                      (const int32_t*)topi, labels, (const RowStats*)stats, out, go, (T*)G, rows, Tlen, V, K, temperature,
                      alpha);

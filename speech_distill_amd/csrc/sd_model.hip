@@ -47,8 +47,8 @@ LayerActs carve(const Sizes& s, char* p) {
 }
 
 struct BwdScratch {
-  char *dx_a, *dx_b, *dxn, *dqkv, *dqk, *dao, *delta, *dgu, *dact, *ws_norm, *ws_qk;
-  int64_t total;
+  char *dx_a, *dx_b, *dxn, *dqkv, *dqk, *dao, *delta, *dgu, *dact, *ws_norm, *ws_qk, *ws_splitk;
+  int64_t total, splitk_bytes;
   BwdScratch(const Sizes& s, char* p) {
     char* p0 = p;
     dx_a = p; p += s.x;
@@ -62,6 +62,8 @@ struct BwdScratch {
     dact = p; p += s.act;
     ws_norm = p; p += al(sd_rmsnorm_bwd_workspace_bytes(s.M, s.h));
     ws_qk = p; p += al(sd_qknorm_rope_bwd_workspace_bytes(s.M, s.Hq, s.Hkv));
+    splitk_bytes = sd_gemm_splitk_workspace_bytes(s.M, s.h, s.V);
+    ws_splitk = p; p += al(splitk_bytes);
     total = p - p0;
   }
 };
@@ -145,7 +147,8 @@ extern "C" int sd_qwen3_backward(const sd_qwen3_dims* d, const sd_qwen3_params* 
 #define ACC(ptr) (acc ? (const void*)(ptr) : (const void*)nullptr)
 
   // lm_head: dxn = dlogits . W ; dW (+)= dlogits^T . xn_f
-  RUN(sd_gemm_bf16(dlogits, p->lm_head, b.dxn, nullptr, s.M, s.h, s.V, s.V, s.h, s.h, 0, 0, 1, stream));
+  RUN(sd_gemm_bf16_splitk(dlogits, p->lm_head, b.dxn, nullptr, s.M, s.h, s.V, s.V, s.h, s.h, 0, 0, 1, b.ws_splitk,
+                          b.splitk_bytes, stream));
   RUN(sd_gemm_bf16(dlogits, xn_f, g->lm_head, ACC(g->lm_head), s.V, s.h, s.M, s.V, s.h, s.h, s.h, 1, 1, stream));
   if (g->embed != g->lm_head && !acc)
     if (hipMemsetAsync(g->embed, 0, (size_t)s.V * s.h * 2, (hipStream_t)stream) != hipSuccess) return SD_ERR_WORKSPACE;

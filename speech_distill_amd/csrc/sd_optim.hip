@@ -4,6 +4,7 @@
 // HBM-bound: 4 streams read + 3 written per parameter, 16 bytes per lane per access.
 #include "sd_common.cuh"
 #include "../../include/sd_hip.h"
+#include "sd_prof.h"
 
 namespace {
 
@@ -79,6 +80,7 @@ extern "C" int sd_adamw_bf16(void* param, const void* grad, void* exp_avg, void*
   const int nb = (int)((n8 + 255) / 256 < 4096 ? (n8 + 255) / 256 : 4096);
   const float bc1 = 1.f - powf(beta1, (float)step);
   const float rbc2 = 1.f / sqrtf(1.f - powf(beta2, (float)step));
+  SdProfScope prof(SD_K_OPTIM, 14.0 * n, (hipStream_t)stream);
   hipLaunchKernelGGL(adamw_kernel, dim3(nb < 1 ? 1 : nb), dim3(256), 0, (hipStream_t)stream, (bf16*)param,
                      (const bf16*)grad, (bf16*)exp_avg, (bf16*)exp_avg_sq, n8, (long)n, lr, beta1, beta2, eps,
                      weight_decay, bc1, rbc2, grad_sumsq, max_grad_norm);

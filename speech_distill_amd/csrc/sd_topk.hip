@@ -9,6 +9,7 @@
 // L2/Infinity Cache by the later radix passes, so HBM sees it about once.
 #include "sd_common.cuh"
 #include "../../include/sd_hip.h"
+#include "sd_prof.h"
 
 namespace {
 
@@ -71,128 +72,13 @@ SD_DEV void pick_bin(const int* hist, int kth, int* sel_bin, int* sel_kth) {
   }
 }
 
-template <typename T, int NPASS>
-__global__ __launch_bounds__(NT) void topk_kernel(const T* __restrict__ X, _Float16* __restrict__ outv,
-                                                  int32_t* __restrict__ outi, float* __restrict__ lse_out, int rows,
-                                                  long row_stride, int V, int K, int KP) {
-  __shared__ float sc[32];
-  __shared__ int hist[256];
-  __shared__ int sel_bin, sel_kth, n_out, tie_base;
-  __shared__ int wave_cnt[16];
-  __shared__ unsigned long long items[KMAX];
-  const int row = blockIdx.x;
-  const T* x = X + (long)row * row_stride;
-  const int lane = lane_id(), wv = threadIdx.x >> 6;
+constexpr int CAP = 2048;  // candidate capacity of the fast path
 
-  // ---- pass 0: log-sum-exp statistics + histogram of the top key byte
-  for (int i = threadIdx.x; i < 256; i += NT) hist[i] = 0;
-  if (threadIdx.x == 0) { n_out = 0; tie_base = 0; }
-  __syncthreads();
-  float m = -INFINITY, s = 0.f;
-  for (int c0 = 0; c0 < V; c0 += NT * 8) {
-    const int c = c0 + threadIdx.x * 8;
-    const bool in = c < V;
-    float f[8];
-    if (in) load8<T>(x + c, f);
-    if (in) {
-      float cm = f[0];
-#pragma unroll
-      for (int e = 1; e < 8; ++e) cm = fmaxf(cm, f[e]);
-      if (cm > m) { s *= __expf(m - cm); m = cm; }
-#pragma unroll
-      for (int e = 0; e < 8; ++e) s += __expf(f[e] - m);
-    }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) hist_add(hist, in ? (int)(f2key(f[e]) >> 24) : 0, in);
-  }
-  const float M = block_max<NT>(m, sc);
-  s = block_sum<NT>(m == -INFINITY ? 0.f : s * __expf(m - M), sc);
-  const float lse = M + __logf(s);
-  if (threadIdx.x == 0 && lse_out) lse_out[row] = lse;
-  __syncthreads();
-  pick_bin(hist, K, &sel_bin, &sel_kth);
-  __syncthreads();
-  uint32_t prefix = (uint32_t)sel_bin;
-  int kth = sel_kth;
-
-  // ---- passes 1..NPASS-1: refine inside the selected bin
-#pragma unroll 1
-  for (int p = 1; p < NPASS; ++p) {
-    const int shift = 24 - 8 * p;
-    for (int i = threadIdx.x; i < 256; i += NT) hist[i] = 0;
-    __syncthreads();
-    for (int c = threadIdx.x * 8; c < V; c += NT * 8) {
-      float f[8];
-      load8<T>(x + c, f);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const uint32_t k = f2key(f[e]);
-        if ((k >> (shift + 8)) == prefix) atomicAdd(&hist[(k >> shift) & 255], 1);
-      }
-    }
-    __syncthreads();
-    pick_bin(hist, kth, &sel_bin, &sel_kth);
-    __syncthreads();
-    prefix = (prefix << 8) | (uint32_t)sel_bin;
-    kth = sel_kth;
-  }
-  // threshold key: top 8*NPASS bits = prefix.  `kth` ties at the threshold are still needed.
-  const uint32_t thr = prefix << (32 - 8 * NPASS);
-  const uint32_t lowmask = (NPASS == 4) ? 0u : ((1u << (32 - 8 * NPASS)) - 1u);
-  const int need_ties = kth;
-
-  // ---- collection, in index order: keys above the threshold always, the first `need_ties` ties
-  for (int c0 = 0; c0 < V; c0 += NT * 8) {
-    const int c = c0 + threadIdx.x * 8;
-    const bool in = c < V;
-    float f[8];
-    uint32_t kk[8];
-    int nt_mine = 0;
-    if (in) load8<T>(x + c, f);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      kk[e] = in ? f2key(f[e]) : 0u;
-      const uint32_t hk = kk[e] & ~lowmask;
-      if (in && hk == thr) ++nt_mine;
-    }
-    // block-wide exclusive scan of the tie counts (index order = thread order within this sweep)
-    int incl = nt_mine;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const int v = __shfl_up(incl, o, 64);
-      if (lane >= o) incl += v;
-    }
-    if (lane == 63) wave_cnt[wv] = incl;
-    __syncthreads();
-    int wbase = tie_base, tot = 0;
-    for (int w2 = 0; w2 < 16; ++w2) {
-      const int cw = wave_cnt[w2];
-      if (w2 < wv) wbase += cw;
-      tot += cw;
-    }
-    int rank = wbase + incl - nt_mine;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      if (!in) continue;
-      const uint32_t hk = kk[e] & ~lowmask;
-      bool take = hk > thr;
-      if (hk == thr) { take = rank < need_ties; ++rank; }
-      if (take) {
-        const int slot = atomicAdd(&n_out, 1);
-        if (slot < KMAX) items[slot] = ((unsigned long long)kk[e] << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)(c + e));
-      }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) tie_base += tot;
-    __syncthreads();
-  }
-  // ---- bitonic sort (descending) of KP >= K composite keys; value first, lower index first on ties
-  for (int i = threadIdx.x; i < KP; i += NT)
-    if (i >= n_out || i >= K) items[i] = 0ull;
-  __syncthreads();
-  for (int size = 2; size <= KP; size <<= 1) {
+// descending bitonic sort of items[0..P2) (P2 a power of two), all NT threads participate
+SD_DEV void bitonic_desc(unsigned long long* items, int P2) {
+  for (int size = 2; size <= P2; size <<= 1) {
     for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      for (int i = threadIdx.x; i < KP / 2; i += NT) {
+      for (int i = threadIdx.x; i < P2 / 2; i += NT) {
         const int lo = ((i / stride) * stride * 2) + (i % stride);
         const int hi = lo + stride;
         const bool desc = ((lo & size) == 0);
@@ -202,6 +88,171 @@ __global__ __launch_bounds__(NT) void topk_kernel(const T* __restrict__ X, _Floa
       __syncthreads();
     }
   }
+}
+
+// Fast path.  Thread t's maximum over its own strided share of the row is one of the row's values, so
+// the K-th largest of the 1024 thread maxima (t0) is a lower bound of the row's K-th largest value:
+// every top-K element has key >= t0, and for non-degenerate rows only ~K..2K elements do.  Those few
+// candidates are sorted exactly (value desc, index asc).  Rows with more than CAP candidates (massive
+// ties) take the general MSB-first radix select below.
+template <typename T, int NPASS>
+__global__ __launch_bounds__(NT) void topk_kernel(const T* __restrict__ X, _Float16* __restrict__ outv,
+                                                  int32_t* __restrict__ outi, float* __restrict__ lse_out, int rows,
+                                                  long row_stride, int V, int K, int KP) {
+  __shared__ float sc[32];
+  __shared__ int hist[256];
+  __shared__ int sel_bin, sel_kth, n_out, tie_base;
+  __shared__ int wave_cnt[16];
+  __shared__ uint32_t tkeys[NT];
+  __shared__ unsigned long long items[CAP];
+  const int row = blockIdx.x;
+  const T* x = X + (long)row * row_stride;
+  const int lane = lane_id(), wv = threadIdx.x >> 6;
+
+  // ---- pass A: log-sum-exp statistics and per-thread maxima (one HBM read of the row)
+  if (threadIdx.x == 0) { n_out = 0; tie_base = 0; }
+  float m = -INFINITY, s = 0.f;
+  for (int c = threadIdx.x * 8; c < V; c += NT * 8) {
+    float f[8];
+    load8<T>(x + c, f);
+    float cm = f[0];
+#pragma unroll
+    for (int e = 1; e < 8; ++e) cm = fmaxf(cm, f[e]);
+    if (cm > m) { s *= __expf(m - cm); m = cm; }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s += __expf(f[e] - m);
+  }
+  tkeys[threadIdx.x] = (m == -INFINITY) ? 0u : f2key(m);
+  const float M = block_max<NT>(m, sc);
+  s = block_sum<NT>(m == -INFINITY ? 0.f : s * __expf(m - M), sc);
+  const float lse = M + __logf(s);
+  if (threadIdx.x == 0 && lse_out) lse_out[row] = lse;
+
+  const int nonempty = min(NT, (V + 7) / 8);
+  bool fast = K <= nonempty;
+  int P2 = KP;
+  if (fast) {
+    // K-th largest of the thread maxima: radix select over 1024 keys
+    uint32_t prefix = 0;
+    int kth = K;
+#pragma unroll 1
+    for (int p = 0; p < NPASS; ++p) {
+      const int shift = 24 - 8 * p;
+      for (int i = threadIdx.x; i < 256; i += NT) hist[i] = 0;
+      __syncthreads();
+      const uint32_t k = tkeys[threadIdx.x];
+      if (p == 0 || (k >> (shift + 8)) == prefix) atomicAdd(&hist[(k >> shift) & 255], 1);
+      __syncthreads();
+      pick_bin(hist, kth, &sel_bin, &sel_kth);
+      __syncthreads();
+      prefix = (prefix << 8) | (uint32_t)sel_bin;
+      kth = sel_kth;
+    }
+    const uint32_t t0 = prefix << (32 - 8 * NPASS);  // low bits zero: a lower bound of the K-th thread max
+    // ---- pass B: gather every element with key >= t0 (row re-read from L2 / Infinity Cache)
+    for (int c = threadIdx.x * 8; c < V; c += NT * 8) {
+      float f[8];
+      load8<T>(x + c, f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const uint32_t k = f2key(f[e]);
+        if (k >= t0) {
+          const int slot = atomicAdd(&n_out, 1);
+          if (slot < CAP) items[slot] = ((unsigned long long)k << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)(c + e));
+        }
+      }
+    }
+    __syncthreads();
+    const int nc = n_out;
+    fast = nc <= CAP;
+    if (fast) {
+      P2 = 2;
+      while (P2 < nc) P2 <<= 1;
+      for (int i = nc + threadIdx.x; i < P2; i += NT) items[i] = 0ull;
+      __syncthreads();
+    } else {
+      __syncthreads();
+      if (threadIdx.x == 0) n_out = 0;
+    }
+  }
+  if (!fast) {
+    // ---- general path: MSB-first radix select over the whole row
+    uint32_t prefix = 0;
+    int kth = K;
+#pragma unroll 1
+    for (int p = 0; p < NPASS; ++p) {
+      const int shift = 24 - 8 * p;
+      for (int i = threadIdx.x; i < 256; i += NT) hist[i] = 0;
+      __syncthreads();
+      for (int c0 = 0; c0 < V; c0 += NT * 8) {
+        const int c = c0 + threadIdx.x * 8;
+        const bool in = c < V;
+        float f[8];
+        if (in) load8<T>(x + c, f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const uint32_t k = in ? f2key(f[e]) : 0u;
+          hist_add(hist, (int)((k >> shift) & 255), in && (p == 0 || (k >> (shift + 8)) == prefix));
+        }
+      }
+      __syncthreads();
+      pick_bin(hist, kth, &sel_bin, &sel_kth);
+      __syncthreads();
+      prefix = (prefix << 8) | (uint32_t)sel_bin;
+      kth = sel_kth;
+    }
+    const uint32_t thr = prefix << (32 - 8 * NPASS);
+    const uint32_t lowmask = (NPASS == 4) ? 0u : ((1u << (32 - 8 * NPASS)) - 1u);
+    const int need_ties = kth;
+    // collection in index order: keys above the threshold always, the first `need_ties` ties
+    for (int c0 = 0; c0 < V; c0 += NT * 8) {
+      const int c = c0 + threadIdx.x * 8;
+      const bool in = c < V;
+      float f[8];
+      uint32_t kk[8];
+      int nt_mine = 0;
+      if (in) load8<T>(x + c, f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        kk[e] = in ? f2key(f[e]) : 0u;
+        if (in && (kk[e] & ~lowmask) == thr) ++nt_mine;
+      }
+      int incl = nt_mine;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += v;
+      }
+      if (lane == 63) wave_cnt[wv] = incl;
+      __syncthreads();
+      int wbase = tie_base, tot = 0;
+      for (int w2 = 0; w2 < 16; ++w2) {
+        const int cw = wave_cnt[w2];
+        if (w2 < wv) wbase += cw;
+        tot += cw;
+      }
+      int rank = wbase + incl - nt_mine;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        if (!in) continue;
+        const uint32_t hk = kk[e] & ~lowmask;
+        bool take = hk > thr;
+        if (hk == thr) { take = rank < need_ties; ++rank; }
+        if (take) {
+          const int slot = atomicAdd(&n_out, 1);
+          if (slot < CAP) items[slot] = ((unsigned long long)kk[e] << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)(c + e));
+        }
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) tie_base += tot;
+      __syncthreads();
+    }
+    P2 = KP;
+    for (int i = threadIdx.x; i < P2; i += NT)
+      if (i >= n_out || i >= K) items[i] = 0ull;
+    __syncthreads();
+  }
+  bitonic_desc(items, P2);
   for (int i = threadIdx.x; i < K; i += NT) {
     const unsigned long long it = items[i];
     const float val = key2f((uint32_t)(it >> 32));
@@ -219,6 +270,7 @@ extern "C" int sd_logsoftmax_topk(const void* logits, void* top_v, void* top_i, 
   int KP = 2;
   while (KP < K) KP <<= 1;
   hipStream_t st = (hipStream_t)stream;
+  SdProfScope prof(SD_K_TOPK, (double)rows * V * (dtype == SD_DTYPE_BF16 ? 2 : 4), st);
   if (dtype == SD_DTYPE_BF16)
     hipLaunchKernelGGL((topk_kernel<bf16, 2>), dim3(rows), dim3(NT), 0, st, (const bf16*)logits, (_Float16*)top_v,
                        (int32_t*)top_i, lse_out, rows, (long)row_stride, V, K, KP);

@@ -40,7 +40,7 @@ def _dt(t):
 
 
 # ------------------------------------------------------------------------------------------ GEMM
-def gemm(a, b, trans_a=False, trans_b=False, residual=None, out=None):
+def gemm(a, b, trans_a=False, trans_b=False, residual=None, out=None, split_k=False):
     """C = op(a) @ op(b) (+ residual).  trans_a: a is stored [K,M]; trans_b=False: b is [N,K]."""
     _need(a, torch.bfloat16, "a"), _need(b, torch.bfloat16, "b")
     K, M = (a.shape if trans_a else a.shape[::-1])
@@ -53,6 +53,14 @@ def gemm(a, b, trans_a=False, trans_b=False, residual=None, out=None):
     if out is None:
         out = torch.empty(M, N, dtype=torch.bfloat16, device=a.device)
     r = None if residual is None else _need(residual, torch.bfloat16, "residual")
+    if split_k:
+        lib = load_lib()
+        nb = lib.sd_gemm_splitk_workspace_bytes(M, N, K)
+        ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=a.device)
+        check(lib.sd_gemm_bf16_splitk(a.data_ptr(), b.data_ptr(), out.data_ptr(), _p(r), M, N, K, a.stride(0), b.stride(0),
+                                      out.stride(0), 0 if r is None else r.stride(0), int(trans_a), int(trans_b),
+                                      ws.data_ptr(), nb, _stream()), "sd_gemm_bf16_splitk")
+        return out
     check(load_lib().sd_gemm_bf16(a.data_ptr(), b.data_ptr(), out.data_ptr(), _p(r), M, N, K, a.stride(0), b.stride(0),
                                   out.stride(0), 0 if r is None else r.stride(0), int(trans_a), int(trans_b), _stream()),
           "sd_gemm_bf16")
@@ -169,6 +177,11 @@ def logsoftmax_topk(logits, k, vocab_size=None):
     lead = logits.shape[:-1]
     Vt = logits.shape[-1]
     V = Vt if vocab_size is None else min(int(vocab_size), Vt)
+    if (Vt % 8) or (logits.data_ptr() % 16):
+        # rows must start 16-byte aligned for the vector loads: take the truncated copy the
+        # reference itself makes at train.py:82-83
+        logits = logits[..., :V].contiguous()
+        Vt = V
     rows = logits.numel() // Vt
     tv = torch.empty(*lead, k, dtype=torch.float16, device=logits.device)
     ti = torch.empty(*lead, k, dtype=torch.int32, device=logits.device)
@@ -233,3 +246,18 @@ def sumsq(x, out):
 def adamw_(p, g, m, v, lr, beta1, beta2, eps, wd, step, grad_sumsq=None, max_norm=0.0):
     check(load_lib().sd_adamw_bf16(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, beta1, beta2,
                                    eps, wd, step, _p(grad_sumsq), max_norm, _stream()), "sd_adamw_bf16")
+
+
+# --------------------------------------------------------------------------------------- profiling
+def prof_begin():
+    check(load_lib().sd_prof_begin(), "sd_prof_begin")
+
+
+def prof_end():
+    """-> {kind: (total_ms, total_work, launches)} measured with HIP events on the launch stream."""
+    import ctypes as C
+    from ._lib import KINDS
+    n = len(KINDS)
+    ms, work, cnt = (C.c_double * n)(), (C.c_double * n)(), (C.c_int64 * n)()
+    check(load_lib().sd_prof_end(ms, work, cnt, n), "sd_prof_end")
+    return {KINDS[i]: (ms[i], work[i], cnt[i]) for i in range(n)}

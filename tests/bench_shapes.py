@@ -1,0 +1,53 @@
+"""GPU micro-benchmark (not a pytest): times every GEMM shape of one BASELINE-config-2 step and the
+row kernels, one launch kind at a time, with torch.cuda events.  Output: gpurun_out/shapes.json"""
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from speech_distill_amd import ops  # noqa: E402
+
+dev = torch.device("cuda:0")
+
+
+def timeit(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters * 1e3  # us
+
+
+def main():
+    M, V = 2048, 159488
+    shapes = []
+    for tag, h, I in (("student", 1024, 3072), ("teacher", 2048, 6144)):
+        for name, N, K in (("qkv", 4096, h), ("o", h, 2048), ("gu", 2 * I, h), ("down", h, I), ("lm_head", V, h)):
+            shapes.append((f"{tag}.{name}.fwd_NT", M, N, K, False, False, False))
+            if tag == "student":
+                shapes.append((f"{tag}.{name}.dX_NN", M, K, N, False, True, name == "lm_head"))
+                shapes.append((f"{tag}.{name}.dW_TN", N, K, M, True, True, False))
+    out = []
+    g = torch.Generator(device=dev).manual_seed(0)
+    for name, m, n, k, ta, tb, sk in shapes:
+        a = torch.randn((k, m) if ta else (m, k), device=dev, generator=g).bfloat16()
+        b = torch.randn((k, n) if tb else (n, k), device=dev, generator=g).bfloat16()
+        c = torch.empty(m, n, device=dev, dtype=torch.bfloat16)
+        us = timeit(lambda: ops.gemm(a, b, ta, tb, out=c, split_k=sk), iters=10 if n > 100000 or k > 100000 else 30)
+        tf = 2.0 * m * n * k / us / 1e6
+        out.append({"name": name, "M": m, "N": n, "K": k, "us": us, "tflops": tf})
+        print(f"{name:28s} M={m:6d} N={n:6d} K={k:6d}  {us:9.1f} us  {tf:7.1f} TF/s", flush=True)
+        del a, b, c
+    os.makedirs("gpurun_out", exist_ok=True)
+    json.dump(out, open("gpurun_out/shapes.json", "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()

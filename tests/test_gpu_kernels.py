@@ -73,6 +73,20 @@ def test_gemm_random(ops, M, N, K, ta, tb, res):
     check_close(f"gemm_{M}x{N}x{K}_ta{int(ta)}tb{int(tb)}r{int(res)}", got, ref, 6e-3, 3e-3)
 
 
+def test_gemm_split_k(ops):
+    """few tiles + long K -> fp32 slabs + fixed-order reduce (the lm_head dX shape class)."""
+    g = torch.Generator().manual_seed(6)
+    M, N, K = 256, 128, 8192
+    a, b = bf(torch.randn(M, K, generator=g)), bf(torch.randn(K, N, generator=g))
+    r = bf(torch.randn(M, N, generator=g))
+    lib = ops.load_lib()
+    assert lib.sd_gemm_splitk_plan(M, N, K) > 1
+    got = ops.gemm(to_dev(a), to_dev(b), False, True, residual=to_dev(r), split_k=True)
+    check_close("gemm_split_k", got, _gemm_ref(a.float(), b.float(), False, True, r.float()), 6e-3, 3e-3)
+    again = ops.gemm(to_dev(a), to_dev(b), False, True, residual=to_dev(r), split_k=True)
+    assert torch.equal(got, again)
+
+
 def test_gemm_accumulate_in_place(ops):
     g = torch.Generator().manual_seed(5)
     a, b = bf(torch.randn(160, 256, generator=g)), bf(torch.randn(160, 136, generator=g))

@@ -55,11 +55,11 @@ def test_qwen3_forward_backward_vs_hf_fixture(sda):
     for k, p in model._params.items():
         gn = float(p.grad.double().norm())
         rn = float(z["gnorm_" + k])
-        record("qwen3_gnorm", name=k, got=gn, ref=rn)
+        record("qwen3_gnorm", param=k, got=gn, ref=rn)
         assert abs(gn - rn) <= 6e-2 * rn + 1e-6, f"{k}: grad norm {gn} vs {rn}"
         if "grad_" + k in z.files:
             c = _cos(p.grad, torch.from_numpy(z["grad_" + k]))
-            record("qwen3_gcos", name=k, cos=c)
+            record("qwen3_gcos", param=k, cos=c)
             worst = min(worst, c)
             assert c >= 0.99, f"{k}: gradient cosine {c}"
     record("qwen3_worst_cos", cos=worst)
@@ -165,7 +165,7 @@ def test_c1_compute_loss_matches_reference(sda, mode, top_k):
                           ("grad_l0_q", "model.layers.0.self_attn.q_proj.weight"),
                           ("grad_l1_down", "model.layers.1.mlp.down_proj.weight")):
             c = _cos(student._params[name].grad, torch.from_numpy(z[f"{mode}_mb{mb}_{key}"]))
-            record(f"c1_{mode}_mb{mb}_cos", name=name, cos=c)
+            record(f"c1_{mode}_mb{mb}_cos", param=name, cos=c)
             assert c >= 0.99, f"{mode} mb{mb} {name}: cosine {c}"
 
 
