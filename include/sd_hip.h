@@ -41,6 +41,8 @@ int sd_gemm_bf16(const void* A, const void* B, void* C, const void* R, int M, in
  * write fp32 slabs into `workspace`, summed in a fixed order by a second kernel (deterministic).
  * sd_gemm_splitk_plan returns the number of slices the library would use (1 = no split). */
 int sd_gemm_splitk_plan(int M, int N, int K);
+/* tuning / tests only: force the tile rows (64|128) and LDS ring depth (2..4) of every later GEMM; bm=0 restores the heuristic */
+void sd_gemm_force_variant(int bm, int nst);
 int64_t sd_gemm_splitk_workspace_bytes(int M, int N, int K);
 int sd_gemm_bf16_splitk(const void* A, const void* B, void* C, const void* R, int M, int N, int K, int64_t lda,
                         int64_t ldb, int64_t ldc, int64_t ldr, int trans_a, int trans_b, void* workspace,

@@ -48,6 +48,7 @@ _vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 PROTOTYPES = {
     "sd_abi_version": (_i, []),
     "sd_gemm_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _i64, _i64, _i, _i, _vp]),
+    "sd_gemm_force_variant": (None, [_i, _i]),
     "sd_gemm_splitk_plan": (_i, [_i, _i, _i]),
     "sd_gemm_splitk_workspace_bytes": (_i64, [_i, _i, _i]),
     "sd_gemm_bf16_splitk": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _i64, _i64, _i, _i, _vp, _i64, _vp]),

@@ -79,7 +79,10 @@ SD_DEV bf16x8 load_frag(const char* lds_tile, int row16_base, int kk, int lane) 
 }
 
 // EPI: 0 = bf16 out, 1 = bf16 out + residual, 2 = fp32 slab out (split-K)
-template <int BM, bool TA, bool TB, int EPI>
+// NST-deep LDS ring: tile t+NST-1 is issued while tile t is computed; the wait for tile t is a COUNTED
+// s_waitcnt vmcnt that leaves the NST-2 younger tiles in flight across the (raw) barrier.  Tiles past
+// the end of K are still issued (their lanes read the zero page), which keeps the count uniform.
+template <int BM, int NST, bool TA, bool TB, int EPI>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B, bf16* C,
                                                         const bf16* R, float* __restrict__ slabs, int M, int N, int K,
                                                         long lda, long ldb, long ldc, long ldr, int tiles_m, int tiles_n,
@@ -87,7 +90,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16* __restrict__
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
   constexpr int MT = BM / 32;  // 16-row MFMA tiles per wave along M
   constexpr int EPI_BYTES = BM * BN * 4;
-  constexpr int SMEM = (2 * STAGE > EPI_BYTES) ? 2 * STAGE : EPI_BYTES;
+  constexpr int SMEM = (NST * STAGE > EPI_BYTES) ? NST * STAGE : EPI_BYTES;
+  constexpr int LOADS = BM / 32 + BN / 32;  // LDS-DMA instructions per wave per tile
   __shared__ __attribute__((aligned(16))) char smem[SMEM];
   const int lane = lane_id();
   const int w = wave_id_uniform();
@@ -106,19 +110,23 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16* __restrict__
   const int kt0 = blockIdx.y * k_tiles_per_split;
   const int kt1 = min(kt_all, kt0 + k_tiles_per_split);
   const int nk = kt1 - kt0;
-  if (nk > 0) {
-    stage_tile<TA, BM>(A, lda, m0, kt0 * BK, M, K, smem, w, lane);
-    stage_tile<TB, BN>(B, ldb, n0, kt0 * BK, N, K, smem + A_BYTES, w, lane);
+  const int k_end = min(K, kt1 * BK);
+#pragma unroll
+  for (int s = 0; s < NST - 1; ++s) {
+    stage_tile<TA, BM>(A, lda, m0, (kt0 + s) * BK, M, k_end, smem + s * STAGE, w, lane);
+    stage_tile<TB, BN>(B, ldb, n0, (kt0 + s) * BK, N, k_end, smem + s * STAGE + A_BYTES, w, lane);
   }
-  __syncthreads();
-
+  int cur_i = 0, nxt_i = NST - 1;
   for (int t = 0; t < nk; ++t) {
-    char* cur = smem + (t & 1) * STAGE;
-    if (t + 1 < nk) {
-      char* nxt = smem + ((t + 1) & 1) * STAGE;
-      stage_tile<TA, BM>(A, lda, m0, (kt0 + t + 1) * BK, M, K, nxt, w, lane);
-      stage_tile<TB, BN>(B, ldb, n0, (kt0 + t + 1) * BK, N, K, nxt + A_BYTES, w, lane);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * LOADS) : "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    {
+      char* nxt = smem + nxt_i * STAGE;
+      stage_tile<TA, BM>(A, lda, m0, (kt0 + t + NST - 1) * BK, M, k_end, nxt, w, lane);
+      stage_tile<TB, BN>(B, ldb, n0, (kt0 + t + NST - 1) * BK, N, k_end, nxt + A_BYTES, w, lane);
     }
+    const char* cur = smem + cur_i * STAGE;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       bf16x8 af[MT], bfr[4];
@@ -131,8 +139,11 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16* __restrict__
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(bfr[j], af[i], acc[i][j]);  // D[n][m]: lane owns 4 consecutive n
     }
-    __syncthreads();  // waits the LDS-DMA of tile t+1 (vmcnt(0)) and fences the reads of tile t
+    cur_i = (cur_i + 1 == NST) ? 0 : cur_i + 1;
+    nxt_i = (nxt_i + 1 == NST) ? 0 : nxt_i + 1;
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the (zero-page) tail tiles before LDS is reused
+  __syncthreads();
 
   // Epilogue: fp32 tile -> LDS (XOR-swizzled 16-byte chunks), then coalesced rows out.
   float* cs = (float*)smem;  // [BM][128] fp32
@@ -200,7 +211,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   }
 }
 
-template <int BM, bool TA, bool TB>
+template <int BM, int NST, bool TA, bool TB>
 int launch(const void* A, const void* B, void* C, const void* R, float* slabs, int splits, int M, int N, int K, long lda,
            long ldb, long ldc, long ldr, hipStream_t st) {
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
@@ -208,7 +219,7 @@ int launch(const void* A, const void* B, void* C, const void* R, float* slabs, i
   const int per = (kt_all + splits - 1) / splits;
   dim3 grid(tiles_m * tiles_n, splits), block(256);
 #define SD_GEMM_GO(EPI)                                                                                              \
-  hipLaunchKernelGGL((gemm_bf16_kernel<BM, TA, TB, EPI>), grid, block, 0, st, (const bf16*)A, (const bf16*)B, (bf16*)C, \
+  hipLaunchKernelGGL((gemm_bf16_kernel<BM, NST, TA, TB, EPI>), grid, block, 0, st, (const bf16*)A, (const bf16*)B, (bf16*)C, \
                      (const bf16*)R, slabs, M, N, K, lda, ldb, ldc, ldr, tiles_m, tiles_n, per)
   if (splits > 1) SD_GEMM_GO(2);
   else if (R) SD_GEMM_GO(1);
@@ -236,18 +247,36 @@ int check_args(const void* A, const void* B, const void* C, const void* R, int M
   return 0;
 }
 
+// variant: 0 = heuristic, else (BM | NST << 8) forced (tuning / tests)
+int g_force_variant = 0;
+
 int dispatch(const void* A, const void* B, void* C, const void* R, float* slabs, int splits, int M, int N, int K,
              long lda, long ldb, long ldc, long ldr, int ta, int tb, hipStream_t st) {
-  // 128-row tiles unless they leave the 256 CUs (2 resident blocks each) under-filled
+  // 128-row tiles unless they leave the 256 CUs under-filled; deeper ring for the small tile
+  // (measured on MI355X, tests/bench_shapes.py --tune: occupancy beats ring depth -- 2 stages = 64 KiB
+  // -> 2 blocks/CU for BM=128, 48 KiB -> 3 for BM=64; a third stage only pays when the grid is ~1 block/CU)
   const long tiles128 = (long)((M + 127) / 128) * ((N + BN - 1) / BN) * splits;
-  const bool small = tiles128 < 448;
+  const long blocks64 = (long)((M + 63) / 64) * ((N + BN - 1) / BN) * splits;
+  int bm = tiles128 < 448 ? 64 : 128;
+  int nst = (bm == 64 && blocks64 <= 320) ? 3 : 2;
+  if (g_force_variant) { bm = g_force_variant & 0xff; nst = g_force_variant >> 8; }
   SdProfScope prof(ta ? SD_K_GEMM_TN : (tb ? SD_K_GEMM_NN : SD_K_GEMM_NT), 2.0 * M * N * K, st);
-#define SD_GO(BM_, TA_, TB_) return launch<BM_, TA_, TB_>(A, B, C, R, slabs, splits, M, N, K, lda, ldb, ldc, ldr, st)
-  if (!ta && !tb) { if (small) SD_GO(64, false, false); SD_GO(128, false, false); }
-  if (!ta && tb) { if (small) SD_GO(64, false, true); SD_GO(128, false, true); }
-  if (ta && tb) { if (small) SD_GO(64, true, true); SD_GO(128, true, true); }
-  if (small) SD_GO(64, true, false);
-  SD_GO(128, true, false);
+#define SD_GO(BM_, NST_, TA_, TB_) \
+  return launch<BM_, NST_, TA_, TB_>(A, B, C, R, slabs, splits, M, N, K, lda, ldb, ldc, ldr, st)
+#define SD_PICK(TA_, TB_)                                   \
+  do {                                                      \
+    if (bm == 64 && nst == 2) SD_GO(64, 2, TA_, TB_);       \
+    if (bm == 64 && nst == 3) SD_GO(64, 3, TA_, TB_);       \
+    if (bm == 64) SD_GO(64, 4, TA_, TB_);                   \
+    if (nst == 2) SD_GO(128, 2, TA_, TB_);                  \
+    if (nst == 4) SD_GO(128, 4, TA_, TB_);                  \
+    SD_GO(128, 3, TA_, TB_);                                \
+  } while (0)
+  if (!ta && !tb) SD_PICK(false, false);
+  if (!ta && tb) SD_PICK(false, true);
+  if (ta && tb) SD_PICK(true, true);
+  SD_PICK(true, false);
+#undef SD_PICK
 #undef SD_GO
 }
 
@@ -259,10 +288,12 @@ extern "C" int sd_gemm_bf16(const void* A, const void* B, void* C, const void* R
   return dispatch(A, B, C, R, nullptr, 1, M, N, K, lda, ldb, ldc, ldr, trans_a, trans_b, (hipStream_t)stream);
 }
 
+extern "C" void sd_gemm_force_variant(int bm, int nst) { g_force_variant = bm ? (bm | (nst << 8)) : 0; }
+
 extern "C" int sd_gemm_splitk_plan(int M, int N, int K) {
   const long tiles = (long)((M + 63) / 64) * ((N + BN - 1) / BN);
   const int kt = (K + BK - 1) / BK;
-  if (tiles >= 512 || kt < 64) return 1;
+  if (tiles >= 512 || kt < 64) return 1;  // measured: pays for K >= 4096 with <= 256 tiles of 64x128, hurts below
   int s = (int)((768 + tiles - 1) / tiles);
   if (s > 8) s = 8;
   if (s > kt / 16) s = kt / 16;

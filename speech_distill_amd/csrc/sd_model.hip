@@ -63,6 +63,10 @@ struct BwdScratch {
     ws_norm = p; p += al(sd_rmsnorm_bwd_workspace_bytes(s.M, s.h));
     ws_qk = p; p += al(sd_qknorm_rope_bwd_workspace_bytes(s.M, s.Hq, s.Hkv));
     splitk_bytes = sd_gemm_splitk_workspace_bytes(s.M, s.h, s.V);
+    for (int k : {s.QKV, 2 * s.I, s.QD, s.I}) {
+      const int64_t b1 = sd_gemm_splitk_workspace_bytes(s.M, s.h, k);
+      splitk_bytes = b1 > splitk_bytes ? b1 : splitk_bytes;
+    }
     ws_splitk = p; p += al(splitk_bytes);
     total = p - p0;
   }
@@ -163,7 +167,8 @@ extern "C" int sd_qwen3_backward(const sd_qwen3_dims* d, const sd_qwen3_params* 
     RUN(sd_gemm_bf16(b.dx_a, w.wdown, b.dact, nullptr, s.M, s.I, s.h, s.h, s.I, s.I, 0, 0, 1, stream));
     RUN(sd_gemm_bf16(b.dx_a, a.act, gw.wdown, ACC(gw.wdown), s.h, s.I, s.M, s.h, s.I, s.I, s.I, 1, 1, stream));
     RUN(sd_swiglu_bwd(b.dact, a.gu, b.dgu, s.M, s.I, stream));
-    RUN(sd_gemm_bf16(b.dgu, w.wgu, b.dxn, nullptr, s.M, s.h, 2 * s.I, 2 * s.I, s.h, s.h, 0, 0, 1, stream));
+    RUN(sd_gemm_bf16_splitk(b.dgu, w.wgu, b.dxn, nullptr, s.M, s.h, 2 * s.I, 2 * s.I, s.h, s.h, 0, 0, 1, b.ws_splitk,
+                            b.splitk_bytes, stream));
     RUN(sd_gemm_bf16(b.dgu, a.xn2, gw.wgu, ACC(gw.wgu), 2 * s.I, s.h, s.M, 2 * s.I, s.h, s.h, s.h, 1, 1, stream));
     RUN(sd_rmsnorm_bwd(b.dxn, a.x_mid, w.ln2, (const float*)a.rstd2, b.dx_a, b.dx_b, gw.ln2, acc, b.ws_norm, s.M, s.h,
                        stream));
@@ -175,7 +180,8 @@ extern "C" int sd_qwen3_backward(const sd_qwen3_dims* d, const sd_qwen3_params* 
                     s.QK, s.QKV, s.QD, s.QK, s.QK, s.QKV, B, T, s.Hq, s.Hkv, 128, scale, stream));
     RUN(sd_qknorm_rope_bwd(b.dqk, a.qkv, w.q_gain, w.k_gain, cos_tab, sin_tab, b.dqkv, gw.q_gain, gw.k_gain, acc, b.ws_qk,
                            s.M, T, s.Hq, s.Hkv, d->eps, stream));
-    RUN(sd_gemm_bf16(b.dqkv, w.wqkv, b.dxn, nullptr, s.M, s.h, s.QKV, s.QKV, s.h, s.h, 0, 0, 1, stream));
+    RUN(sd_gemm_bf16_splitk(b.dqkv, w.wqkv, b.dxn, nullptr, s.M, s.h, s.QKV, s.QKV, s.h, s.h, 0, 0, 1, b.ws_splitk,
+                            b.splitk_bytes, stream));
     RUN(sd_gemm_bf16(b.dqkv, a.xn1, gw.wqkv, ACC(gw.wqkv), s.QKV, s.h, s.M, s.QKV, s.h, s.h, s.h, 1, 1, stream));
     RUN(sd_rmsnorm_bwd(b.dxn, a.x_in, w.ln1, (const float*)a.rstd1, b.dx_b, b.dx_a, gw.ln1, acc, b.ws_norm, s.M, s.h,
                        stream));

@@ -36,14 +36,26 @@ def main():
                 shapes.append((f"{tag}.{name}.dW_TN", N, K, M, True, True, False))
     out = []
     g = torch.Generator(device=dev).manual_seed(0)
+    lib = ops.load_lib()
+    variants = [(0, 0), (128, 2), (64, 2), (64, 3)] if "--tune" in sys.argv else [(0, 0)]
     for name, m, n, k, ta, tb, sk in shapes:
         a = torch.randn((k, m) if ta else (m, k), device=dev, generator=g).bfloat16()
         b = torch.randn((k, n) if tb else (n, k), device=dev, generator=g).bfloat16()
         c = torch.empty(m, n, device=dev, dtype=torch.bfloat16)
-        us = timeit(lambda: ops.gemm(a, b, ta, tb, out=c, split_k=sk), iters=10 if n > 100000 or k > 100000 else 30)
-        tf = 2.0 * m * n * k / us / 1e6
-        out.append({"name": name, "M": m, "N": n, "K": k, "us": us, "tflops": tf})
-        print(f"{name:28s} M={m:6d} N={n:6d} K={k:6d}  {us:9.1f} us  {tf:7.1f} TF/s", flush=True)
+        row = {"name": name, "M": m, "N": n, "K": k}
+        line = f"{name:26s} M={m:6d} N={n:6d} K={k:6d} "
+        for bm, nst in variants:
+            for use_sk in ([False, True] if ("--tune" in sys.argv and k >= 2048 and (m // 64) * (n // 128) < 512) else [sk]):
+                lib.sd_gemm_force_variant(bm, nst)
+                us = timeit(lambda: ops.gemm(a, b, ta, tb, out=c, split_k=use_sk), iters=8 if n > 100000 or k > 100000 else 25)
+                tf = 2.0 * m * n * k / us / 1e6
+                key = ("auto" if bm == 0 else f"{bm}x{nst}") + ("+sk" if use_sk else "")
+                row[key] = round(tf, 1)
+                row[key + "_us"] = round(us, 1)
+                line += f" {key}:{tf:6.0f}"
+        lib.sd_gemm_force_variant(0, 0)
+        out.append(row)
+        print(line, flush=True)
         del a, b, c
     os.makedirs("gpurun_out", exist_ok=True)
     json.dump(out, open("gpurun_out/shapes.json", "w"), indent=1)
