@@ -1,0 +1,68 @@
+"""CPU checks of the drop-in boundary: the C-ABI library loads, exports every symbol that
+include/sd_hip.h declares, and the ctypes table binds exactly that set (no compute without a GPU)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+
+def _declared():
+    txt = open(os.path.join(ROOT, "include", "sd_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    names = set(re.findall(r"\b(sd_[a-z0-9_]+)\s*\(", txt))
+    names.discard("sd_stage_cb")
+    return names
+
+
+def test_header_symbols_are_exported_and_bound():
+    import speech_distill_amd as sda
+    from speech_distill_amd import _lib
+    if not os.path.exists(sda.lib_path()):
+        import __graft_entry__
+        __graft_entry__.build()
+    lib = ctypes.CDLL(sda.lib_path())
+    declared = _declared()
+    assert len(declared) >= 25
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/sd_hip.h but not exported by libsd_hip.so"
+    assert set(_lib.PROTOTYPES) == declared, (set(_lib.PROTOTYPES) ^ declared)
+    assert sda.load_lib().sd_abi_version() == 1
+
+
+def test_workspace_queries_run_without_gpu():
+    import speech_distill_amd as sda
+    from speech_distill_amd import _lib
+    lib = sda.load_lib()
+    d = _lib.Dims(159488, 1024, 3072, 28, 16, 8, 128, 1, 1e-6, 0)
+    train = lib.sd_qwen3_acts_bytes(ctypes.byref(d), 4, 512, 1)
+    infer = lib.sd_qwen3_acts_bytes(ctypes.byref(d), 4, 512, 0)
+    assert 2e9 < train < 4e9 and infer < train / 10
+    assert lib.sd_kdloss_stats_bytes(4, 512) == 4 * 512 * 32
+    assert lib.sd_gemm_splitk_plan(2048, 1024, 159488) > 1 and lib.sd_gemm_splitk_plan(2048, 6144, 1024) == 1
+
+
+def test_cpu_tensors_are_rejected_not_routed_to_a_fallback():
+    import torch
+    import speech_distill_amd as sda
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        sda.DistillationLoss()(torch.randn(1, 4, 64), torch.tensor([[1, 2, 3, 4]]), teacher_logits=torch.randn(1, 4, 64))
+    with pytest.raises(ValueError, match="Either teacher_logits or top_k must be provided"):
+        sda.DistillationLoss()(torch.randn(1, 4, 64), torch.tensor([[1, 2, 3, 4]]))
+
+
+def test_product_never_imports_the_oracle():
+    """oracle/ is test infrastructure: only tests/, smoke() and bench.py's cpu_baseline may touch it."""
+    pat = re.compile(r"^\s*(from|import)\s+oracle\b", re.M)
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "speech_distill_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cuh")):
+                assert not pat.search(open(os.path.join(dirpath, f)).read()), f
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    body = bench.split("def cpu_baseline", 1)[1].split("\ndef ", 1)
+    outside = bench.split("def cpu_baseline", 1)[0] + body[1]
+    # the only other use is the FLOP-count constant table
+    assert all("flops_per_token" in m.group(0) or "STUDENT_06B" in m.group(0)
+               for m in re.finditer(r".*oracle.*", outside) if "import" in m.group(0))

@@ -1,0 +1,115 @@
+"""CPU tests of the plug-in's HOST logic (train.py:43-116 control flow) with the compute back-ends
+replaced by the oracle.  This is the checker standing in for the kernels in a test; the product
+default back-ends are the HIP kernels and refuse CPU tensors (tests/test_cabi.py)."""
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from oracle import distill_loss as L
+
+
+class TinyLM(nn.Module):
+    def __init__(self, V=32, h=8):
+        super().__init__()
+        self.emb = nn.Embedding(V, h)
+        self.out = nn.Linear(h, V, bias=False)
+        self.calls = 0
+
+    def forward(self, input_ids=None, attention_mask=None, labels=None, **kw):
+        self.calls += 1
+        return type("O", (dict,), {"logits": property(lambda s: s["logits"])})(logits=self.out(self.emb(input_ids)))
+
+
+class OracleLoss(nn.Module):
+    def __init__(self, T, a):
+        super().__init__()
+        self.T, self.a, self.seen = T, a, []
+
+    def forward(self, student_logits, labels, teacher_logits=None, teacher_top_k_v=None, teacher_top_k_i=None,
+                speech_token_mask=None):
+        self.seen.append("dense" if teacher_logits is not None else "sparse")
+        return L.distill_loss(student_logits, labels, teacher_logits, teacher_top_k_v, teacher_top_k_i,
+                              speech_token_mask, self.T, self.a, acc=torch.float32)
+
+
+def make(top_k=4, quantized=False, logging_steps=1):
+    from transformers import TrainingArguments
+    from speech_distill_amd.trainer import DistillationTrainer
+    torch.manual_seed(0)
+    student, teacher = TinyLM(), TinyLM()
+    args = TrainingArguments(output_dir=tempfile.mkdtemp(), use_cpu=True, report_to=[], logging_steps=logging_steps,
+                             remove_unused_columns=False, label_names=["labels"], save_strategy="no")
+    tr = DistillationTrainer(model=student, args=args, teacher_model=teacher, temperature=2.0, alpha=0.5, top_k=top_k,
+                             is_quantized_teacher=quantized)
+    tr.distill_loss_fn = OracleLoss(2.0, 0.5)
+    tr._extract_topk = lambda logits, k, V: L.extract_topk(logits, k, V)
+    logged = []
+    tr.log = lambda d, *a, **k: logged.append(d)
+    return tr, student, teacher, logged
+
+
+def batch():
+    ids = torch.randint(0, 32, (2, 6), generator=torch.Generator().manual_seed(1))
+    labels = ids.clone()
+    labels[:, :2] = -100
+    return {"input_ids": ids, "attention_mask": torch.ones_like(ids), "labels": labels,
+            "teacher_input_ids": ids.clone(), "teacher_attention_mask": torch.ones_like(ids)}
+
+
+def test_on_the_fly_sparse_path_and_logging():
+    tr, student, teacher, logged = make(top_k=4)
+    inputs = batch()
+    loss = tr.compute_loss(student, inputs)
+    assert tr.distill_loss_fn.seen == ["sparse"] and teacher.calls == 1 and student.calls == 1
+    assert loss.requires_grad and set(logged[-1]) == {"student_loss", "teacher_loss", "distill_loss"}
+    # compute_loss mutates the dict exactly like the reference: the five keys and labels are popped
+    assert set(inputs) == {"input_ids", "attention_mask"}
+
+
+def test_pre_extracted_topk_skips_teacher_forward():
+    tr, student, teacher, _ = make(top_k=4)
+    b = batch()
+    b["teacher_top_k_v"] = -torch.rand(2, 6, 4).half()
+    b["teacher_top_k_i"] = torch.randint(0, 32, (2, 6, 4)).int()
+    tr.compute_loss(student, b)
+    assert teacher.calls == 0 and tr.distill_loss_fn.seen == ["sparse"]
+
+
+@pytest.mark.parametrize("kw", [dict(top_k=0), dict(quantized=True)])
+def test_dense_branch(kw):
+    tr, student, teacher, _ = make(**kw)
+    tr.compute_loss(student, batch())
+    assert tr.distill_loss_fn.seen == ["dense"] and teacher.calls == 1
+
+
+def test_no_teacher_ids_falls_back_to_student_inputs_and_return_outputs():
+    tr, student, teacher, _ = make()
+    b = batch()
+    del b["teacher_input_ids"], b["teacher_attention_mask"]
+    loss, out = tr.compute_loss(student, b, return_outputs=True)
+    assert teacher.calls == 1 and out.logits.shape == (2, 6, 32)
+
+
+def test_logging_cadence_follows_global_step():
+    tr, student, _, logged = make(logging_steps=10)
+    tr.state.global_step = 3
+    tr.compute_loss(student, batch())
+    assert not logged
+    tr.state.global_step = 20
+    tr.compute_loss(student, batch())
+    assert len(logged) == 1
+
+
+def test_matches_reference_value():
+    """Same numbers as the oracle step on the same tiny models (control flow does not change the maths)."""
+    tr, student, teacher, logged = make(top_k=4)
+    b = batch()
+    loss = tr.compute_loss(student, dict(b))
+    with torch.no_grad():
+        s, t = student(input_ids=b["input_ids"]).logits, teacher(input_ids=b["input_ids"]).logits
+    v, i = L.extract_topk(t, 4, 32)
+    ref = L.distill_loss(s, b["labels"], teacher_top_k_v=v, teacher_top_k_i=i, temperature=2.0, alpha=0.5)
+    np.testing.assert_allclose(float(loss), float(ref[0]), rtol=1e-5)
