@@ -89,6 +89,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="do not record per-launch HIP events in the timed region")
     ap.add_argument("--cpu-sample-tokens", type=int, default=512)
+    ap.add_argument("--serial-teacher", action="store_true", help="teacher forward on the student's stream (no overlap)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -119,15 +120,26 @@ def main():
     reducer = ddp.attach(student) if world > 1 else None
     batch = synthetic_batch(args.batch, args.seq_len, rank, dev)
 
+    side = None if args.serial_teacher else torch.cuda.Stream(device=dev)
+
+    def teacher_topk():
+        t_logits = teacher(input_ids=batch["teacher_input_ids"],
+                           attention_mask=batch["teacher_attention_mask"]).logits           # train.py:60-69
+        return ops.logsoftmax_topk(t_logits, args.top_k, VOCAB)                             # train.py:80-91
+
     def step():
         student.zero_grad()
+        with torch.no_grad():
+            if side is None:
+                tv, ti = teacher_topk()
+            else:  # the frozen teacher is independent of the student: run it on a second HIP stream
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    tv, ti = teacher_topk()
         logits = student(input_ids=batch["input_ids"], attention_mask=batch["attention_mask"],
                          labels=batch["labels"]).logits                                     # train.py:54
-        with torch.no_grad():
-            t_logits = teacher(input_ids=batch["teacher_input_ids"],
-                               attention_mask=batch["teacher_attention_mask"]).logits       # train.py:60-69
-            tv, ti = ops.logsoftmax_topk(t_logits, args.top_k, logits.size(-1))             # train.py:80-91
-            del t_logits
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
         total, task, distill, teach = loss_fn(logits, batch["labels"], teacher_top_k_v=tv, teacher_top_k_i=ti)
         total.backward()                                                                    # HF trainer.py:1961
         return total, task, distill, teach

@@ -52,7 +52,7 @@ def test_gemm_exact_integers(ops, ta, tb):
     b = torch.randint(-3, 4, (K, N) if tb else (N, K), generator=g).float()
     a[0, :] += 1.0  # asymmetric
     got = ops.gemm(to_dev(bf(a)), to_dev(bf(b)), ta, tb).float().cpu()
-    ref = _gemm_ref(a, b, ta, tb).float()
+    ref = _gemm_ref(a, b, ta, tb).float().bfloat16().float()
     bad = (got != ref).nonzero()
     record(f"gemm_exact_ta{int(ta)}_tb{int(tb)}", n_bad=int(bad.shape[0]))
     assert bad.shape[0] == 0, f"{bad.shape[0]} wrong entries, first {bad[:5].tolist()} got {got[tuple(bad[0])]} ref {ref[tuple(bad[0])]}"
@@ -71,6 +71,24 @@ def test_gemm_random(ops, M, N, K, ta, tb, res):
     got = ops.gemm(to_dev(a), to_dev(b), ta, tb, residual=None if r is None else to_dev(r))
     ref = _gemm_ref(a.float(), b.float(), ta, tb, None if r is None else r.float())
     check_close(f"gemm_{M}x{N}x{K}_ta{int(ta)}tb{int(tb)}r{int(res)}", got, ref, 6e-3, 3e-3)
+
+
+@pytest.mark.parametrize("bm,nst", [(256, 3), (256, 2), (128, 3), (64, 4), (64, 2)])
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, True)])
+def test_gemm_forced_variants_exact(ops, bm, nst, ta, tb):
+    """every tile height / ring depth the heuristic can pick, on integer data (must be exact), ragged edges."""
+    g = torch.Generator().manual_seed(bm + nst)
+    M, N, K = 520, 264, 200
+    a = torch.randint(-3, 4, (K, M) if ta else (M, K), generator=g).float()
+    b = torch.randint(-3, 4, (K, N) if tb else (N, K), generator=g).float()
+    lib = ops.load_lib()
+    lib.sd_gemm_force_variant(bm, nst)
+    try:
+        got = ops.gemm(to_dev(bf(a)), to_dev(bf(b)), ta, tb).float().cpu()
+    finally:
+        lib.sd_gemm_force_variant(0, 0)
+    # integer sums are exact in fp32; the bf16 output rounds values above 256 (RNE), so round the reference too
+    assert torch.equal(got, _gemm_ref(a, b, ta, tb).float().bfloat16().float())
 
 
 def test_gemm_split_k(ops):

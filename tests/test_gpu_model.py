@@ -213,3 +213,40 @@ def test_full_size_student_step_properties(sda):
     assert bool(torch.isfinite(grad.float()).all())
     assert float(grad.float().abs().max()) > 0
     assert res[1][0] == total and torch.equal(res[1][2], grad), "step is not deterministic"
+
+
+def test_real_width_step_vs_oracle(sda):
+    """Real widths of BASELINE config 2 (student h=1024/I=3072, teacher h=2048/I=6144, 16/8 heads, V=159 488)
+    at depth 2 and B=1,T=96 so the fp32 CPU oracle finishes in seconds: loss within 2e-2 (bf16 weights given to
+    both sides), top-K values identical up to fp16 ulp, gradient norms within 8e-2."""
+    from oracle import qwen3 as Q
+    from oracle import step as S
+    from speech_distill_amd import ops
+    st, te = Q.Qwen3Shape(159488, 1024, 3072, 2, 16, 8), Q.Qwen3Shape(159488, 2048, 6144, 2, 16, 8)
+    sw = {k: v.bfloat16().float() for k, v in Q.init_weights(st, seed=11).items()}
+    tw = {k: v.bfloat16().float() for k, v in Q.init_weights(te, seed=12).items()}
+    student = _build(sda, (159488, 1024, 3072, 2, 16, 8), sw)
+    teacher = _build(sda, (159488, 2048, 6144, 2, 16, 8), tw)
+    teacher.eval().requires_grad_(False)
+    g = torch.Generator().manual_seed(5)
+    B, T = 1, 96
+    ids = torch.randint(0, 159488, (B, T), generator=g)
+    ids[:, 24:] = torch.randint(152927, 159488, (B, T - 24), generator=g)
+    labels = ids.clone()
+    labels[:, :25] = -100
+    batch = {"input_ids": ids, "attention_mask": torch.ones_like(ids), "labels": labels}
+    ref = S.distill_step(sw, st, tw, te, batch, 2.0, 0.5, top_k=128, acc=torch.float32)
+    ids_d = to_dev(ids)
+    logits = student(input_ids=ids_d).logits
+    with torch.no_grad():
+        tv, ti = ops.logsoftmax_topk(teacher(input_ids=ids_d).logits, 128, 159488)
+    out = sda.DistillationLoss(2.0, 0.5)(logits, to_dev(labels), teacher_top_k_v=tv, teacher_top_k_i=ti)
+    out[0].backward()
+    got = [float(x) for x in out]
+    want = [float(ref[k]) for k in ("total", "task", "distill", "teacher")]
+    record("real_width_step", got=got, ref=want)
+    np.testing.assert_allclose(got[:3], want[:3], rtol=2e-2)
+    for k in ("model.layers.1.mlp.down_proj.weight", "model.layers.0.self_attn.q_proj.weight", "model.norm.weight"):
+        gn, rn = float(student._params[k].grad.double().norm()), float(ref["grads"][k].double().norm())
+        record("real_width_gnorm", param=k, got=gn, ref=rn)
+        assert abs(gn - rn) <= 8e-2 * rn, (k, gn, rn)
