@@ -89,6 +89,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="do not record per-launch HIP events in the timed region")
     ap.add_argument("--cpu-sample-tokens", type=int, default=512)
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL over xGMI) | gloo (single-GPU rehearsal of the N>1 path)")
+    ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--serial-teacher", action="store_true", help="teacher forward on the student's stream (no overlap)")
     args = ap.parse_args()
 
@@ -99,8 +101,13 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if args.single_device:
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
     dev = torch.device("cuda", local_rank)
 
     import speech_distill_amd as sda
@@ -170,10 +177,18 @@ def main():
         prof_dt = time.perf_counter() - tp
         prof = ops.prof_end()
     if world > 1:
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tmax = torch.tensor([dt], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax)
     losses = [float(x) for x in out]
+    grad_sync_ok = None
+    if world > 1:  # after the all-reduce every rank must hold the same averaged gradient
+        cs = student.flat_grad.float().abs().sum().double().reshape(1)
+        cs = cs if args.backend == "nccl" else cs.cpu()
+        lo, hi = cs.clone(), cs.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        grad_sync_ok = bool(float(hi) - float(lo) <= 1e-6 * abs(float(hi)))
 
     if rank == 0:
         tokens = world * args.batch * args.seq_len * args.steps
@@ -190,6 +205,7 @@ def main():
                        "parallelism": f"dp{world}" if world > 1 else "single"},
             "step_flops_per_token_algorithmic": f_tok,
             "step_mfma_frac": (tokens / dt) * f_tok / world / (MFMA_PEAK_TFLOPS * 1e12),
+            "grad_sync_ok": grad_sync_ok,
             "loss": {"total": losses[0], "task": losses[1], "distill": losses[2], "teacher": losses[3]},
         }
         if prof is not None:

@@ -68,9 +68,9 @@ int sd_qknorm_rope_bwd(const void* dqk, const void* qkv, const void* q_gain, con
 int sd_swiglu_fwd(const void* gate_up, void* act, int M, int I, void* stream);
 int sd_swiglu_bwd(const void* dact, const void* gate_up, void* dgate_up, int M, int I, void* stream);
 
-/* ---- embedding (HF:381) and its deterministic scatter-add backward (dE += rows of dx) */
+/* ---- embedding (HF:381) and its deterministic scatter-add backward (dE += scale * rows of dx) */
 int sd_embedding_fwd(const int64_t* ids, const void* E, void* x, int M, int H, int V, void* stream);
-int sd_embedding_bwd(const int64_t* ids, const void* dx, void* dE, int M, int H, int V, void* stream);
+int sd_embedding_bwd(const int64_t* ids, const void* dx, void* dE, int M, int H, int V, float scale, void* stream);
 
 /* ---- causal GQA flash attention, head_dim 128 (flash_attn via train.py:160,177; maths HF:185-207).
  * q [B*T, ldq] head hq at column hq*128; k, v likewise per kv head; o [B*T, ldo]; lse fp32 [B,Hq,T].
@@ -146,14 +146,17 @@ int sd_qwen3_forward(const sd_qwen3_dims* d, const sd_qwen3_params* p, const int
  * finish one group of gradients have been enqueued on `stream`: stage = SD_STAGE_HEAD (lm_head dW
  * + final norm, before any layer), layer index L-1..0 (that layer's 8 tensors), SD_STAGE_EMBED (the
  * embedding scatter-add, last).  A data-parallel caller records an event there and starts that
- * bucket's RCCL all-reduce on a second stream, overlapping it with the rest of backward. */
+ * bucket's RCCL all-reduce on a second stream, overlapping it with the rest of backward.
+ * dx0_out (nullable, bf16 [B*T,h]): when given, the gradient w.r.t. the embedding OUTPUT is written there and
+ * the local embedding scatter-add is skipped -- the data-parallel caller then reduces the dense (lm_head)
+ * part of the tied gradient early and exchanges only the B*T touched rows (ddp.py). */
 #define SD_STAGE_HEAD (-1)
 #define SD_STAGE_EMBED (-2)
 typedef void (*sd_stage_cb)(int stage, void* user);
 int sd_qwen3_backward(const sd_qwen3_dims* d, const sd_qwen3_params* p, const sd_qwen3_params* g, const int64_t* ids,
                       const int32_t* kv_len, const void* cos_tab, const void* sin_tab, void* acts, int64_t acts_bytes,
                       void* dlogits, void* scratch, int64_t scratch_bytes, int B, int T, int accumulate,
-                      sd_stage_cb on_grads_ready, void* cb_user, void* stream);
+                      void* dx0_out, sd_stage_cb on_grads_ready, void* cb_user, void* stream);
 
 /* ---- optional live timing (bench.py): HIP events around every launch, on the launch stream.
  * kinds index the arrays of sd_prof_end; work = algorithmic FLOPs (GEMM, attention) or bytes (others). */

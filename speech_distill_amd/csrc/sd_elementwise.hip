@@ -315,7 +315,7 @@ __global__ __launch_bounds__(256) void embedding_fwd_kernel(const int64_t* __res
 // Deterministic scatter-add: the block of the FIRST token carrying an id sums every token row with
 // that id (fixed order) and adds the total to dE[id]; other blocks exit.  No atomics, no sort.
 __global__ __launch_bounds__(256) void embedding_bwd_kernel(const int64_t* __restrict__ ids, const bf16* __restrict__ dx,
-                                                            bf16* dE, int M, int H, int V) {
+                                                            bf16* dE, int M, int H, int V, float scale) {
   __shared__ int first_flag;
   const int m = blockIdx.x;
   const long id = ids[m];
@@ -327,14 +327,18 @@ __global__ __launch_bounds__(256) void embedding_bwd_kernel(const int64_t* __res
   __syncthreads();
   if (!first_flag) return;
   for (int c = threadIdx.x * 8; c < H; c += 2048) {
-    float acc[8], f[8];
-    unpack8(*(const bf16x8*)(dE + id * H + c), acc);
+    float acc[8], f[8], base[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
     for (int i = m; i < M; ++i) {
       if (ids[i] != id) continue;
       unpack8(*(const bf16x8*)(dx + (long)i * H + c), f);
 #pragma unroll
       for (int e = 0; e < 8; ++e) acc[e] += f[e];
     }
+    unpack8(*(const bf16x8*)(dE + id * H + c), base);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = base[e] + scale * acc[e];
     *(bf16x8*)(dE + id * H + c) = pack8(acc);
   }
 }
@@ -458,10 +462,11 @@ extern "C" int sd_embedding_fwd(const int64_t* ids, const void* E, void* x, int 
   return 0;
 }
 
-extern "C" int sd_embedding_bwd(const int64_t* ids, const void* dx, void* dE, int M, int H, int V, void* stream) {
+extern "C" int sd_embedding_bwd(const int64_t* ids, const void* dx, void* dE, int M, int H, int V, float scale,
+                                void* stream) {
   if (M <= 0 || (H & 7)) return SD_ERR_SHAPE;
   SdProfScope prof(SD_K_EMBED, 6.0 * M * H, ST);
-  hipLaunchKernelGGL(embedding_bwd_kernel, dim3(M), dim3(256), 0, ST, ids, (const bf16*)dx, (bf16*)dE, M, H, V);
+  hipLaunchKernelGGL(embedding_bwd_kernel, dim3(M), dim3(256), 0, ST, ids, (const bf16*)dx, (bf16*)dE, M, H, V, scale);
   SD_CHECK_LAUNCH();
   return 0;
 }

@@ -135,7 +135,8 @@ extern "C" int sd_qwen3_forward(const sd_qwen3_dims* d, const sd_qwen3_params* p
 extern "C" int sd_qwen3_backward(const sd_qwen3_dims* d, const sd_qwen3_params* p, const sd_qwen3_params* g,
                                  const int64_t* ids, const int32_t* kv_len, const void* cos_tab, const void* sin_tab,
                                  void* acts, int64_t acts_bytes, void* dlogits, void* scratch, int64_t scratch_bytes, int B,
-                                 int T, int accumulate, sd_stage_cb on_grads_ready, void* cb_user, void* stream) {
+                                 int T, int accumulate, void* dx0_out, sd_stage_cb on_grads_ready, void* cb_user,
+                                 void* stream) {
   if (d->head_dim != 128) return SD_ERR_UNSUPPORTED;
   Sizes s(d, B, T);
   if (acts_bytes < sd_qwen3_acts_bytes(d, B, T, 1)) return SD_ERR_WORKSPACE;
@@ -183,11 +184,11 @@ extern "C" int sd_qwen3_backward(const sd_qwen3_dims* d, const sd_qwen3_params* 
     RUN(sd_gemm_bf16_splitk(b.dqkv, w.wqkv, b.dxn, nullptr, s.M, s.h, s.QKV, s.QKV, s.h, s.h, 0, 0, 1, b.ws_splitk,
                             b.splitk_bytes, stream));
     RUN(sd_gemm_bf16(b.dqkv, a.xn1, gw.wqkv, ACC(gw.wqkv), s.QKV, s.h, s.M, s.QKV, s.h, s.h, s.h, 1, 1, stream));
-    RUN(sd_rmsnorm_bwd(b.dxn, a.x_in, w.ln1, (const float*)a.rstd1, b.dx_b, b.dx_a, gw.ln1, acc, b.ws_norm, s.M, s.h,
-                       stream));
+    RUN(sd_rmsnorm_bwd(b.dxn, a.x_in, w.ln1, (const float*)a.rstd1, b.dx_b, (l == 0 && dx0_out) ? dx0_out : b.dx_a,
+                       gw.ln1, acc, b.ws_norm, s.M, s.h, stream));
     if (on_grads_ready) on_grads_ready(l, cb_user);
   }
-  RUN(sd_embedding_bwd(ids, b.dx_a, g->embed, s.M, s.h, s.V, stream));
+  if (!dx0_out) RUN(sd_embedding_bwd(ids, b.dx_a, g->embed, s.M, s.h, s.V, 1.0f, stream));
   if (on_grads_ready) on_grads_ready(SD_STAGE_EMBED, cb_user);
 #undef ACC
   return 0;

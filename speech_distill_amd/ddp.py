@@ -23,19 +23,24 @@ import torch.distributed as dist
 STAGE_HEAD, STAGE_EMBED = -1, -2
 
 
-def bucket_plan(layer_ranges, embed_range, norm_range, numel, layers_per_bucket=1):
+def bucket_plan(layer_ranges, embed_range, norm_range, numel, layers_per_bucket=1, split_embedding=False):
     """-> list of (stage_that_closes_it, start, end) in backward completion order.
 
-    The tied embedding / lm_head gradient is only final after the embedding scatter-add
-    (STAGE_EMBED), the final-norm gain after STAGE_HEAD."""
+    The tied embedding / lm_head gradient (27 % of the student: 327 MB) is only final after the embedding
+    scatter-add (STAGE_EMBED), i.e. at the very end of backward.  With ``split_embedding`` its dense
+    lm_head part is instead reduced right after STAGE_HEAD -- under the whole layer backward -- and the
+    scatter part is exchanged as rows (FlatGradAllReduce._exchange_embedding_rows)."""
     plan = [(STAGE_HEAD, norm_range[0], norm_range[1])]
+    if split_embedding:
+        plan.append((STAGE_HEAD, embed_range[0], embed_range[1]))
     L = len(layer_ranges)
     l = L - 1
     while l >= 0:
         lo = max(0, l - layers_per_bucket + 1)
         plan.append((lo, layer_ranges[lo][0], layer_ranges[l][1]))
         l = lo - 1
-    plan.append((STAGE_EMBED, embed_range[0], embed_range[1]))
+    if not split_embedding:
+        plan.append((STAGE_EMBED, embed_range[0], embed_range[1]))
     if numel > norm_range[1]:  # untied lm_head lives after the final norm; final once the head stage is done
         plan.insert(1, (STAGE_HEAD, norm_range[1], numel))
     return plan
@@ -44,13 +49,18 @@ def bucket_plan(layer_ranges, embed_range, norm_range, numel, layers_per_bucket=
 class FlatGradAllReduce:
     """Averages ``flat_grad`` over the process group, bucket by bucket, overlapped with backward."""
 
-    def __init__(self, flat_grad_getter, plan, group=None, comm_stream=None):
+    def __init__(self, flat_grad_getter, plan, group=None, comm_stream=None, split_embedding=False):
         self._get = flat_grad_getter
         self.plan = plan
+        self.split_embedding = split_embedding
+        self._emb = None
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.sync = True
-        self.cuda = torch.cuda.is_available()
+        backend = dist.get_backend(group) if dist.is_initialized() else "none"
+        # RCCL ("nccl"): in-stream all_reduce(AVG) on a dedicated communication stream.  gloo (CPU tests,
+        # single-GPU rehearsal): no AVG and no stream semantics -> async SUM, scaled in finish().
+        self.cuda = torch.cuda.is_available() and backend == "nccl"
         self.comm = comm_stream if comm_stream is not None else (torch.cuda.Stream() if self.cuda else None)
         self._works = []
         self.issued = []  # (stage, start, end) actually reduced in the current step (for tests / stats)
@@ -66,10 +76,49 @@ class FlatGradAllReduce:
 
     def begin_step(self):
         self._works, self.issued = [], []
+        self._emb = None
+
+    def wants_split_embedding(self):
+        return self.split_embedding and self.sync and self.world > 1
+
+    def set_embedding_exchange(self, ids, dx0, embed_grad):
+        """Called by the model before backward: token ids [M], buffer that will receive d loss / d embedding
+        output [M,h], and the [V,h] gradient view the rows are scattered into."""
+        self._emb = (ids, dx0, embed_grad)
+
+    def _exchange_embedding_rows(self):
+        """All-gather (ids, rows) of every rank, then the same deterministic scatter-add on every rank:
+        dE += (1/W) sum_r scatter(ids_r, rows_r).  Runs after the dense part's all-reduce (same stream)."""
+        from . import ops
+        ids, dx0, embed_grad = self._emb
+        W = self.world
+        all_ids = [torch.empty_like(ids) for _ in range(W)]
+        all_rows = [torch.empty_like(dx0) for _ in range(W)]
+        dist.all_gather(all_ids, ids, group=self.group)
+        dist.all_gather(all_rows, dx0, group=self.group)
+        for r in range(W):
+            ops.embedding_bwd(all_ids[r], all_rows[r], embed_grad, scale=1.0 / W)
 
     def on_stage(self, stage):
         """Host callback from the backward runner: grads of `stage` are enqueued on the compute stream."""
         if not self.sync or self.world == 1:
+            return
+        if stage == STAGE_EMBED and self._emb is not None:
+            if self.cuda:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream())
+                self.comm.wait_event(ev)
+                with torch.cuda.stream(self.comm):
+                    self._exchange_embedding_rows()
+            else:
+                if self._emb[1].is_cuda:
+                    torch.cuda.current_stream().synchronize()
+                for w, chunk in self._works:  # the dense part must be averaged before rows are added
+                    w.wait()
+                    chunk.div_(self.world)
+                self._works = []
+                self._exchange_embedding_rows()
+            self.issued.append((stage, -1, -1))
             return
         flat = self._get()
         for (st, a, b) in self.plan:
@@ -82,7 +131,9 @@ class FlatGradAllReduce:
                 self.comm.wait_event(ev)
                 with torch.cuda.stream(self.comm):
                     dist.all_reduce(chunk, op=dist.ReduceOp.AVG, group=self.group)
-            else:  # gloo has no AVG: sum then scale
+            else:  # gloo has no AVG: sum then scale (device tensors: wait for the producing kernels first)
+                if chunk.is_cuda:
+                    torch.cuda.current_stream().synchronize()
                 w = dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
                 self._works.append((w, chunk))
             self.issued.append((st, a, b))
@@ -97,10 +148,12 @@ class FlatGradAllReduce:
         self._works = []
 
 
-def attach(model, group=None, layers_per_bucket=1):
+def attach(model, group=None, layers_per_bucket=1, split_embedding=True):
     """Wire a HipQwen3ForCausalLM's backward stage callback to overlapped all-reduces."""
-    plan = bucket_plan(model.layer_ranges, model.embed_range, model.norm_range, model.numel_flat, layers_per_bucket)
-    red = FlatGradAllReduce(lambda: model.flat_grad, plan, group)
+    split_embedding = split_embedding and model.dims.tie_word_embeddings
+    plan = bucket_plan(model.layer_ranges, model.embed_range, model.norm_range, model.numel_flat, layers_per_bucket,
+                       split_embedding)
+    red = FlatGradAllReduce(lambda: model.flat_grad, plan, group, split_embedding=split_embedding)
     model._stage_cb = red.on_stage
     model._reducer = red
     model.no_sync = red.no_sync

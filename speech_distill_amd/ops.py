@@ -141,9 +141,10 @@ def embedding_fwd(ids, E):
     return x
 
 
-def embedding_bwd(ids, dx, dE):
+def embedding_bwd(ids, dx, dE, scale=1.0):
     V, H = dE.shape
-    check(load_lib().sd_embedding_bwd(ids.data_ptr(), dx.data_ptr(), dE.data_ptr(), ids.numel(), H, V, _stream()),
+    check(load_lib().sd_embedding_bwd(ids.data_ptr(), dx.data_ptr(), dE.data_ptr(), ids.numel(), H, V, float(scale),
+                                      _stream()),
           "sd_embedding_bwd")
     return dE
 

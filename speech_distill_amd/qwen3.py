@@ -279,8 +279,14 @@ class HipQwen3ForCausalLM(nn.Module):
         B, T = input_ids.shape
         accumulate = self._ensure_grads()
         red = getattr(self, "_reducer", None)
+        dx0 = None
         if red is not None:
             red.begin_step()
+            if red.wants_split_embedding():
+                # tied embedding/lm_head gradient: the dense lm_head part is all-reduced at the START of
+                # backward; only the B*T rows touched by the embedding lookup are exchanged at the end
+                dx0 = torch.empty(B * T, self.dims.hidden_size, dtype=torch.bfloat16, device=input_ids.device)
+                red.set_embedding_exchange(input_ids.reshape(-1), dx0, self._params["model.embed_tokens.weight"].grad)
         if not dlogits.is_contiguous():
             dlogits = dlogits.contiguous()
         cos, sin = self._tables(T, input_ids.device)
@@ -291,7 +297,7 @@ class HipQwen3ForCausalLM(nn.Module):
         check(lib.sd_qwen3_backward(C.byref(self._cdims), C.byref(self._cparams), C.byref(self._cgrads),
                                     input_ids.data_ptr(), _p(kv_len), cos.data_ptr(), sin.data_ptr(), acts.data_ptr(),
                                     acts.numel(), dlogits.data_ptr(), scratch.data_ptr(), sbytes, B, T, int(accumulate),
-                                    cb, None, _stream()), "sd_qwen3_backward")
+                                    _p(dx0), cb, None, _stream()), "sd_qwen3_backward")
         if red is not None:
             red.finish()
 

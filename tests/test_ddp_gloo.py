@@ -32,6 +32,13 @@ def test_bucket_plan_covers_every_element_once_in_backward_order():
         assert stages[0] == ddp.STAGE_HEAD and stages[-1] == ddp.STAGE_EMBED
         layer_stages = [s for s in stages if s >= 0]
         assert layer_stages == sorted(layer_stages, reverse=True)
+    # split tied embedding: its dense part closes with the head stage (start of backward), nothing waits for the end
+    plan = ddp.bucket_plan(ranges, embed, norm, numel, 1, split_embedding=True)
+    cover = torch.zeros(numel, dtype=torch.int32)
+    for _, a, b in plan:
+        cover[a:b] += 1
+    assert bool((cover == 1).all()) and all(s != ddp.STAGE_EMBED for s, _, _ in plan)
+    assert (ddp.STAGE_HEAD, embed[0], embed[1]) in plan
 
 
 def _free_port():
