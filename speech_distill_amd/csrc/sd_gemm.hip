@@ -60,6 +60,47 @@ SD_DEV void stage_tile(const bf16* __restrict__ g, long ld, int row0, int k0, in
   }
 }
 
+// Fast staging: buffer_load_dwordx4 ... lds through a buffer descriptor.  The per-lane byte offset of
+// every DMA piece is loop-invariant (computed once, kept in VGPRs), the K advance is one scalar add,
+// and the hardware range check returns zeros past the end of the operand -- no per-step address
+// arithmetic, compares or exec-mask juggling (the checked path costs ~90 SALU + ~30 VALU per K-step).
+template <bool TX, int ROWS, int NW>
+struct FastStage {
+  static constexpr int NI = ROWS / (8 * NW);
+  int voff[NI];
+#if defined(__HIP_DEVICE_COMPILE__)  // the descriptor type only exists in the device pass; the host pass only needs the stub
+  __amdgpu_buffer_rsrc_t rsrc;
+#endif
+  long kstep;  // bytes per k element step of BK
+  SD_DEV void init(const bf16* g, long ld, int row0, unsigned num_bytes, int w, int lane) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)g, 0, (int)num_bytes, 0x00020000);
+#endif
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int p = (w * NI + i) * 64 + lane;
+      if constexpr (!TX) {
+        const int r = p >> 3, s = p & 7, c = s ^ (r & 7);
+        voff[i] = (int)((((long)(row0 + r)) * ld + c * 8) * 2);
+      } else {
+        constexpr int UPR = ROWS / 8;
+        const int k = p / UPR, u = p % UPR;
+        const int ch = (u >> 1) ^ swz_t<ROWS>(k);
+        voff[i] = (int)((((long)k) * ld + row0 + ch * 16 + (u & 1) * 8) * 2);
+      }
+    }
+    kstep = TX ? ld * 2 : 2;
+  }
+  SD_DEV void issue(int k0, char* lds_tile, int w) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int soff = (int)(k0 * kstep);
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (SD_LDS void*)(lds_tile + (w * NI + i) * 1024), 16, voff[i], soff, 0, 0);
+#endif
+  }
+};
+
 // Fragment of 16 rows x 32 k for v_mfma_f32_16x16x32_bf16: lane l holds row (l&15), k = 8(l>>4)+j.
 template <bool TX, int ROWS>
 SD_DEV bf16x8 load_frag(const char* lds_tile, int row16_base, int kk, int lane) {
@@ -82,8 +123,8 @@ SD_DEV bf16x8 load_frag(const char* lds_tile, int row16_base, int kk, int lane) 
 // NST-deep LDS ring: tile t+NST-1 is issued while tile t is computed; the wait for tile t is a COUNTED
 // s_waitcnt vmcnt that leaves the NST-2 younger tiles in flight across the (raw) barrier.  Tiles past
 // the end of K are still issued (their lanes read the zero page), which keeps the count uniform.
-template <int BM, int NST, bool TA, bool TB, int EPI>
-__global__ __launch_bounds__(BM == 256 ? 512 : 256) void gemm_bf16_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B, bf16* C,
+template <int BM, int NST, bool TA, bool TB, int EPI, bool FAST>
+__global__ __launch_bounds__(BM == 256 ? 512 : 256, (BM == 256 ? 2 : (NST * (BM + 128) * 128 <= 80 * 1024 ? 2 : 1))) void gemm_bf16_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B, bf16* C,
                                                         const bf16* R, float* __restrict__ slabs, int M, int N, int K,
                                                         long lda, long ldb, long ldc, long ldr, int tiles_m, int tiles_n,
                                                         int k_tiles_per_split) {
@@ -114,10 +155,21 @@ __global__ __launch_bounds__(BM == 256 ? 512 : 256) void gemm_bf16_kernel(const 
   const int kt1 = min(kt_all, kt0 + k_tiles_per_split);
   const int nk = kt1 - kt0;
   const int k_end = min(K, kt1 * BK);
+  FastStage<TA, BM, NW> fa;
+  FastStage<TB, BN, NW> fb;
+  if constexpr (FAST) {
+    fa.init(A, lda, m0, (unsigned)((TA ? ((long)(K - 1) * lda + M) : ((long)(M - 1) * lda + K)) * 2), w, lane);
+    fb.init(B, ldb, n0, (unsigned)((TB ? ((long)(K - 1) * ldb + N) : ((long)(N - 1) * ldb + K)) * 2), w, lane);
+  }
 #pragma unroll
   for (int s = 0; s < NST - 1; ++s) {
-    stage_tile<TA, BM, NW>(A, lda, m0, (kt0 + s) * BK, M, k_end, smem + s * STAGE, w, lane);
-    stage_tile<TB, BN, NW>(B, ldb, n0, (kt0 + s) * BK, N, k_end, smem + s * STAGE + A_BYTES, w, lane);
+    if constexpr (FAST) {
+      fa.issue((kt0 + s) * BK, smem + s * STAGE, w);
+      fb.issue((kt0 + s) * BK, smem + s * STAGE + A_BYTES, w);
+    } else {
+      stage_tile<TA, BM, NW>(A, lda, m0, (kt0 + s) * BK, M, k_end, smem + s * STAGE, w, lane);
+      stage_tile<TB, BN, NW>(B, ldb, n0, (kt0 + s) * BK, N, k_end, smem + s * STAGE + A_BYTES, w, lane);
+    }
   }
   int cur_i = 0, nxt_i = NST - 1;
   for (int t = 0; t < nk; ++t) {
@@ -126,8 +178,13 @@ __global__ __launch_bounds__(BM == 256 ? 512 : 256) void gemm_bf16_kernel(const 
     asm volatile("" ::: "memory");
     {
       char* nxt = smem + nxt_i * STAGE;
-      stage_tile<TA, BM, NW>(A, lda, m0, (kt0 + t + NST - 1) * BK, M, k_end, nxt, w, lane);
-      stage_tile<TB, BN, NW>(B, ldb, n0, (kt0 + t + NST - 1) * BK, N, k_end, nxt + A_BYTES, w, lane);
+      if constexpr (FAST) {
+        fa.issue((kt0 + t + NST - 1) * BK, nxt, w);
+        fb.issue((kt0 + t + NST - 1) * BK, nxt + A_BYTES, w);
+      } else {
+        stage_tile<TA, BM, NW>(A, lda, m0, (kt0 + t + NST - 1) * BK, M, k_end, nxt, w, lane);
+        stage_tile<TB, BN, NW>(B, ldb, n0, (kt0 + t + NST - 1) * BK, N, k_end, nxt + A_BYTES, w, lane);
+      }
     }
     const char* cur = smem + cur_i * STAGE;
 #pragma unroll
@@ -214,6 +271,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   }
 }
 
+bool g_no_fast_stage = false;  // tests / A-B measurements: force the checked staging path
+
 template <int BM, int NST, bool TA, bool TB>
 int launch(const void* A, const void* B, void* C, const void* R, float* slabs, int splits, int M, int N, int K, long lda,
            long ldb, long ldc, long ldr, hipStream_t st) {
@@ -221,9 +280,24 @@ int launch(const void* A, const void* B, void* C, const void* R, float* slabs, i
   const int kt_all = (K + BK - 1) / BK;
   const int per = (kt_all + splits - 1) / splits;
   dim3 grid(tiles_m * tiles_n, splits), block(BM == 256 ? 512 : 256);
+  // descriptor-based staging needs every k >= K to read as zero in at least one operand (transposed
+  // operands get that from the hardware range check; two K-contiguous ones need K % 64 == 0) and 31-bit offsets
+  const long bytes_a = (TA ? ((long)(K - 1) * lda + M) : ((long)(M - 1) * lda + K)) * 2;
+  const long bytes_b = (TB ? ((long)(K - 1) * ldb + N) : ((long)(N - 1) * ldb + K)) * 2;
+  const long span = ((long)kt_all + 4) * BK * 2 * (TA ? lda : 1) + bytes_a;
+  const long span_b = ((long)kt_all + 4) * BK * 2 * (TB ? ldb : 1) + bytes_b;
+  const bool fast = !g_no_fast_stage && (TA || TB || (K % BK) == 0) && span < 0x7fffffffL && span_b < 0x7fffffffL;
 #define SD_GEMM_GO(EPI)                                                                                              \
-  hipLaunchKernelGGL((gemm_bf16_kernel<BM, NST, TA, TB, EPI>), grid, block, 0, st, (const bf16*)A, (const bf16*)B, (bf16*)C, \
-                     (const bf16*)R, slabs, M, N, K, lda, ldb, ldc, ldr, tiles_m, tiles_n, per)
+  do {                                                                                                               \
+    if (fast)                                                                                                        \
+      hipLaunchKernelGGL((gemm_bf16_kernel<BM, NST, TA, TB, EPI, true>), grid, block, 0, st, (const bf16*)A,          \
+                         (const bf16*)B, (bf16*)C, (const bf16*)R, slabs, M, N, K, lda, ldb, ldc, ldr, tiles_m,       \
+                         tiles_n, per);                                                                              \
+    else                                                                                                             \
+      hipLaunchKernelGGL((gemm_bf16_kernel<BM, NST, TA, TB, EPI, false>), grid, block, 0, st, (const bf16*)A,         \
+                         (const bf16*)B, (bf16*)C, (const bf16*)R, slabs, M, N, K, lda, ldb, ldc, ldr, tiles_m,       \
+                         tiles_n, per);                                                                              \
+  } while (0)
   if (splits > 1) SD_GEMM_GO(2);
   else if (R) SD_GEMM_GO(1);
   else SD_GEMM_GO(0);
@@ -261,7 +335,7 @@ int dispatch(const void* A, const void* B, void* C, const void* R, float* slabs,
   const long tiles128 = (long)((M + 127) / 128) * ((N + BN - 1) / BN) * splits;
   const long blocks64 = (long)((M + 63) / 64) * ((N + BN - 1) / BN) * splits;
   int bm = tiles128 < 448 ? 64 : 128;
-  int nst = (bm == 64 && blocks64 <= 320) ? 3 : 2;
+  int nst = (bm == 64 && (blocks64 <= 320 || (!ta && !tb && blocks64 <= 512))) ? 3 : 2;
   // lm_head-class NT GEMMs (thousands of tiles): 256x128 tiles, 8 waves, 3-deep ring (+10 % measured)
   if (!ta && !tb && (long)((M + 255) / 256) * ((N + BN - 1) / BN) >= 2048 && M >= 1024) { bm = 256; nst = 3; }
   if (g_force_variant) { bm = g_force_variant & 0xffff; nst = g_force_variant >> 16; }
@@ -295,7 +369,11 @@ extern "C" int sd_gemm_bf16(const void* A, const void* B, void* C, const void* R
   return dispatch(A, B, C, R, nullptr, 1, M, N, K, lda, ldb, ldc, ldr, trans_a, trans_b, (hipStream_t)stream);
 }
 
-extern "C" void sd_gemm_force_variant(int bm, int nst) { g_force_variant = bm ? (bm | (nst << 16)) : 0; }
+extern "C" void sd_gemm_force_variant(int bm, int nst) {
+  g_no_fast_stage = (nst & 0x100) != 0;  // nst | 0x100: checked (pointer) staging instead of buffer descriptors
+  nst &= 0xff;
+  g_force_variant = bm ? (bm | (nst << 16)) : 0;
+}
 
 extern "C" int sd_gemm_splitk_plan(int M, int N, int K) {
   const long tiles = (long)((M + 63) / 64) * ((N + BN - 1) / BN);

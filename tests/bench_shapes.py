@@ -37,7 +37,7 @@ def main():
     out = []
     g = torch.Generator(device=dev).manual_seed(0)
     lib = ops.load_lib()
-    variants = [(0, 0), (128, 2), (256, 2), (256, 3)] if "--tune" in sys.argv else [(0, 0)]
+    variants = [(0, 0), (128, 2), (128, 3), (64, 2), (64, 3), (256, 3), (128, 2 | 0x100)] if "--tune" in sys.argv else [(0, 0)]
     for name, m, n, k, ta, tb, sk in shapes:
         a = torch.randn((k, m) if ta else (m, k), device=dev, generator=g).bfloat16()
         b = torch.randn((k, n) if tb else (n, k), device=dev, generator=g).bfloat16()
@@ -49,7 +49,7 @@ def main():
                 lib.sd_gemm_force_variant(bm, nst)
                 us = timeit(lambda: ops.gemm(a, b, ta, tb, out=c, split_k=use_sk), iters=8 if n > 100000 or k > 100000 else 25)
                 tf = 2.0 * m * n * k / us / 1e6
-                key = ("auto" if bm == 0 else f"{bm}x{nst}") + ("+sk" if use_sk else "")
+                key = ("auto" if bm == 0 else f"{bm}x{nst & 0xff}" + ("chk" if nst & 0x100 else "")) + ("+sk" if use_sk else "")
                 row[key] = round(tf, 1)
                 row[key + "_us"] = round(us, 1)
                 line += f" {key}:{tf:6.0f}"

@@ -73,7 +73,7 @@ def test_gemm_random(ops, M, N, K, ta, tb, res):
     check_close(f"gemm_{M}x{N}x{K}_ta{int(ta)}tb{int(tb)}r{int(res)}", got, ref, 6e-3, 3e-3)
 
 
-@pytest.mark.parametrize("bm,nst", [(256, 3), (256, 2), (128, 3), (64, 4), (64, 2)])
+@pytest.mark.parametrize("bm,nst", [(256, 3), (256, 2), (128, 3), (64, 4), (64, 2), (128, 2 | 0x100), (64, 3 | 0x100)])
 @pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, True)])
 def test_gemm_forced_variants_exact(ops, bm, nst, ta, tb):
     """every tile height / ring depth the heuristic can pick, on integer data (must be exact), ragged edges."""
