@@ -147,6 +147,9 @@ int sd_qwen3_forward(const sd_qwen3_dims* d, const sd_qwen3_params* p, const int
  * + final norm, before any layer), layer index L-1..0 (that layer's 8 tensors), SD_STAGE_EMBED (the
  * embedding scatter-add, last).  A data-parallel caller records an event there and starts that
  * bucket's RCCL all-reduce on a second stream, overlapping it with the rest of backward.
+ * side_stream (nullable hipStream_t): when given, the weight-gradient GEMMs of a layer (dW = dY^T X, which
+ * nothing else in the layer depends on) are launched there and overlap the dX chain on `stream`; ordering
+ * is by HIP events, `stream` has waited for all of them when the call returns (and before each callback).
  * dx0_out (nullable, bf16 [B*T,h]): when given, the gradient w.r.t. the embedding OUTPUT is written there and
  * the local embedding scatter-add is skipped -- the data-parallel caller then reduces the dense (lm_head)
  * part of the tied gradient early and exchanges only the B*T touched rows (ddp.py). */
@@ -156,7 +159,7 @@ typedef void (*sd_stage_cb)(int stage, void* user);
 int sd_qwen3_backward(const sd_qwen3_dims* d, const sd_qwen3_params* p, const sd_qwen3_params* g, const int64_t* ids,
                       const int32_t* kv_len, const void* cos_tab, const void* sin_tab, void* acts, int64_t acts_bytes,
                       void* dlogits, void* scratch, int64_t scratch_bytes, int B, int T, int accumulate,
-                      void* dx0_out, sd_stage_cb on_grads_ready, void* cb_user, void* stream);
+                      void* dx0_out, sd_stage_cb on_grads_ready, void* cb_user, void* side_stream, void* stream);
 
 /* ---- optional live timing (bench.py): HIP events around every launch, on the launch stream.
  * kinds index the arrays of sd_prof_end; work = algorithmic FLOPs (GEMM, attention) or bytes (others). */

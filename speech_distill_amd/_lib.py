@@ -76,7 +76,7 @@ PROTOTYPES = {
     "sd_qwen3_bwd_scratch_bytes": (_i64, [C.POINTER(Dims), _i, _i]),
     "sd_qwen3_forward": (_i, [C.POINTER(Dims), C.POINTER(Params), _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i, _i, _i, _vp]),
     "sd_qwen3_backward": (_i, [C.POINTER(Dims), C.POINTER(Params), C.POINTER(Params), _vp, _vp, _vp, _vp, _vp, _i64,
-                               _vp, _vp, _i64, _i, _i, _i, _vp, STAGE_CB, _vp, _vp]),
+                               _vp, _vp, _i64, _i, _i, _i, _vp, STAGE_CB, _vp, _vp, _vp]),
 }
 
 

@@ -330,14 +330,21 @@ int g_force_variant = 0;
 int dispatch(const void* A, const void* B, void* C, const void* R, float* slabs, int splits, int M, int N, int K,
              long lda, long ldb, long ldc, long ldr, int ta, int tb, hipStream_t st) {
   // 128-row tiles unless they leave the 256 CUs under-filled; deeper ring for the small tile
-  // (measured on MI355X, tests/bench_shapes.py --tune: occupancy beats ring depth -- 2 stages = 64 KiB
-  // -> 2 blocks/CU for BM=128, 48 KiB -> 3 for BM=64; a third stage only pays when the grid is ~1 block/CU)
+  // Picked from tests/bench_shapes.py --tune --cold on MI355X (weight operand HBM-cold, as in the real step
+  // where every layer streams its own weights).  NT/NN read weights: latency-bound on HBM misses, so large
+  // tiles / deeper rings win whenever the grid still covers the 256 CUs; TN (dW) reads two warm activations.
+  const long tiles256 = (long)((M + 255) / 256) * ((N + BN - 1) / BN) * splits;
   const long tiles128 = (long)((M + 127) / 128) * ((N + BN - 1) / BN) * splits;
   const long blocks64 = (long)((M + 63) / 64) * ((N + BN - 1) / BN) * splits;
-  int bm = tiles128 < 448 ? 64 : 128;
-  int nst = (bm == 64 && (blocks64 <= 320 || (!ta && !tb && blocks64 <= 512))) ? 3 : 2;
-  // lm_head-class NT GEMMs (thousands of tiles): 256x128 tiles, 8 waves, 3-deep ring (+10 % measured)
-  if (!ta && !tb && (long)((M + 255) / 256) * ((N + BN - 1) / BN) >= 2048 && M >= 1024) { bm = 256; nst = 3; }
+  int bm, nst;
+  if (!ta && !tb) {  // forward linear
+    if (tiles256 >= 256) { bm = 256; nst = 3; }
+    else if (tiles128 >= 256) { bm = 128; nst = 3; }
+    else { bm = 64; nst = blocks64 <= 320 ? 4 : 3; }
+  } else {
+    bm = tiles128 < 448 ? 64 : 128;
+    nst = (bm == 64 && blocks64 <= 320) ? 3 : 2;
+  }
   if (g_force_variant) { bm = g_force_variant & 0xffff; nst = g_force_variant >> 16; }
   SdProfScope prof(ta ? SD_K_GEMM_TN : (tb ? SD_K_GEMM_NN : SD_K_GEMM_NT), 2.0 * M * N * K, st);
 #define SD_GO(BM_, NST_, TA_, TB_) \

@@ -74,6 +74,17 @@ struct BwdScratch {
 
 #define RUN(call) do { int e__ = (call); if (e__) return e__; } while (0)
 
+// Events ordering the optional side stream against the main one (created once, timing disabled).
+hipEvent_t g_ev[8];
+bool g_ev_ready = false;
+bool ensure_events() {
+  if (g_ev_ready) return true;
+  for (auto& e : g_ev)
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return false;
+  g_ev_ready = true;
+  return true;
+}
+
 }  // namespace
 
 extern "C" int sd_abi_version(void) { return 1; }
@@ -136,7 +147,7 @@ extern "C" int sd_qwen3_backward(const sd_qwen3_dims* d, const sd_qwen3_params* 
                                  const int64_t* ids, const int32_t* kv_len, const void* cos_tab, const void* sin_tab,
                                  void* acts, int64_t acts_bytes, void* dlogits, void* scratch, int64_t scratch_bytes, int B,
                                  int T, int accumulate, void* dx0_out, sd_stage_cb on_grads_ready, void* cb_user,
-                                 void* stream) {
+                                 void* side_stream, void* stream) {
   if (d->head_dim != 128) return SD_ERR_UNSUPPORTED;
   Sizes s(d, B, T);
   if (acts_bytes < sd_qwen3_acts_bytes(d, B, T, 1)) return SD_ERR_WORKSPACE;
@@ -150,6 +161,12 @@ extern "C" int sd_qwen3_backward(const sd_qwen3_dims* d, const sd_qwen3_params* 
   char* xn_f = rstd_f + s.rstd;
   const int acc = accumulate ? 1 : 0;
 #define ACC(ptr) (acc ? (const void*)(ptr) : (const void*)nullptr)
+  hipStream_t s1 = (hipStream_t)stream, s2 = (hipStream_t)side_stream;
+  if (s2 && !ensure_events()) return SD_ERR_WORKSPACE;
+  void* wstream = s2 ? side_stream : stream;  // where weight-gradient GEMMs go
+  // main -> side: "this buffer is final"; side -> main: "this layer's dW GEMMs have read their inputs"
+#define SIGNAL(i) do { if (s2) { if (hipEventRecord(g_ev[i], s1) != hipSuccess || hipStreamWaitEvent(s2, g_ev[i], 0) != hipSuccess) return SD_ERR_WORKSPACE; } } while (0)
+#define JOIN() do { if (s2) { if (hipEventRecord(g_ev[7], s2) != hipSuccess || hipStreamWaitEvent(s1, g_ev[7], 0) != hipSuccess) return SD_ERR_WORKSPACE; } } while (0)
 
   // lm_head: dxn = dlogits . W ; dW (+)= dlogits^T . xn_f
   RUN(sd_gemm_bf16_splitk(dlogits, p->lm_head, b.dxn, nullptr, s.M, s.h, s.V, s.V, s.h, s.h, 0, 0, 1, b.ws_splitk,
@@ -165,25 +182,30 @@ extern "C" int sd_qwen3_backward(const sd_qwen3_dims* d, const sd_qwen3_params* 
     const sd_qwen3_layer& w = p->layers_host[l];
     const sd_qwen3_layer& gw = g->layers_host[l];
     // MLP
+    SIGNAL(0);  // dx_a final
+    RUN(sd_gemm_bf16(b.dx_a, a.act, gw.wdown, ACC(gw.wdown), s.h, s.I, s.M, s.h, s.I, s.I, s.I, 1, 1, wstream));
     RUN(sd_gemm_bf16(b.dx_a, w.wdown, b.dact, nullptr, s.M, s.I, s.h, s.h, s.I, s.I, 0, 0, 1, stream));
-    RUN(sd_gemm_bf16(b.dx_a, a.act, gw.wdown, ACC(gw.wdown), s.h, s.I, s.M, s.h, s.I, s.I, s.I, 1, 1, stream));
     RUN(sd_swiglu_bwd(b.dact, a.gu, b.dgu, s.M, s.I, stream));
+    SIGNAL(1);  // dgu final
     RUN(sd_gemm_bf16_splitk(b.dgu, w.wgu, b.dxn, nullptr, s.M, s.h, 2 * s.I, 2 * s.I, s.h, s.h, 0, 0, 1, b.ws_splitk,
                             b.splitk_bytes, stream));
-    RUN(sd_gemm_bf16(b.dgu, a.xn2, gw.wgu, ACC(gw.wgu), 2 * s.I, s.h, s.M, 2 * s.I, s.h, s.h, s.h, 1, 1, stream));
+    RUN(sd_gemm_bf16(b.dgu, a.xn2, gw.wgu, ACC(gw.wgu), 2 * s.I, s.h, s.M, 2 * s.I, s.h, s.h, s.h, 1, 1, wstream));
     RUN(sd_rmsnorm_bwd(b.dxn, a.x_mid, w.ln2, (const float*)a.rstd2, b.dx_a, b.dx_b, gw.ln2, acc, b.ws_norm, s.M, s.h,
                        stream));
+    SIGNAL(2);  // dx_b final
     // attention
     RUN(sd_gemm_bf16(b.dx_b, w.wo, b.dao, nullptr, s.M, s.QD, s.h, s.h, s.QD, s.QD, 0, 0, 1, stream));
-    RUN(sd_gemm_bf16(b.dx_b, a.ao, gw.wo, ACC(gw.wo), s.h, s.QD, s.M, s.h, s.QD, s.QD, s.QD, 1, 1, stream));
+    RUN(sd_gemm_bf16(b.dx_b, a.ao, gw.wo, ACC(gw.wo), s.h, s.QD, s.M, s.h, s.QD, s.QD, s.QD, 1, 1, wstream));
     RUN(sd_attn_bwd(a.qk, a.qk + (int64_t)s.QD * 2, a.qkv + (int64_t)(s.QD + s.KD) * 2, a.ao, b.dao, (const float*)a.lse,
                     (float*)b.delta, b.dqk, b.dqk + (int64_t)s.QD * 2, b.dqkv + (int64_t)(s.QD + s.KD) * 2, kv_len, s.QK,
                     s.QK, s.QKV, s.QD, s.QK, s.QK, s.QKV, B, T, s.Hq, s.Hkv, 128, scale, stream));
     RUN(sd_qknorm_rope_bwd(b.dqk, a.qkv, w.q_gain, w.k_gain, cos_tab, sin_tab, b.dqkv, gw.q_gain, gw.k_gain, acc, b.ws_qk,
                            s.M, T, s.Hq, s.Hkv, d->eps, stream));
+    SIGNAL(3);  // dqkv final
+    RUN(sd_gemm_bf16(b.dqkv, a.xn1, gw.wqkv, ACC(gw.wqkv), s.QKV, s.h, s.M, s.QKV, s.h, s.h, s.h, 1, 1, wstream));
     RUN(sd_gemm_bf16_splitk(b.dqkv, w.wqkv, b.dxn, nullptr, s.M, s.h, s.QKV, s.QKV, s.h, s.h, 0, 0, 1, b.ws_splitk,
                             b.splitk_bytes, stream));
-    RUN(sd_gemm_bf16(b.dqkv, a.xn1, gw.wqkv, ACC(gw.wqkv), s.QKV, s.h, s.M, s.QKV, s.h, s.h, s.h, 1, 1, stream));
+    JOIN();  // the layer's dW GEMMs are done before dx_a / dgu / dx_b / dqkv are overwritten and before the callback
     RUN(sd_rmsnorm_bwd(b.dxn, a.x_in, w.ln1, (const float*)a.rstd1, b.dx_b, (l == 0 && dx0_out) ? dx0_out : b.dx_a,
                        gw.ln1, acc, b.ws_norm, s.M, s.h, stream));
     if (on_grads_ready) on_grads_ready(l, cb_user);
@@ -191,5 +213,7 @@ extern "C" int sd_qwen3_backward(const sd_qwen3_dims* d, const sd_qwen3_params* 
   if (!dx0_out) RUN(sd_embedding_bwd(ids, b.dx_a, g->embed, s.M, s.h, s.V, 1.0f, stream));
   if (on_grads_ready) on_grads_ready(SD_STAGE_EMBED, cb_user);
 #undef ACC
+#undef SIGNAL
+#undef JOIN
   return 0;
 }

@@ -164,6 +164,8 @@ class HipQwen3ForCausalLM(nn.Module):
         self._cparams, self._clayers = self._c_struct(self.flat)
         self._cgrads = None
         self._stage_cb = None  # python callable(stage) set by the data-parallel wrapper
+        self.overlap_dw = True
+        self._side_stream = None
         if init_std:
             self.init_weights(seed, init_std)
 
@@ -297,9 +299,18 @@ class HipQwen3ForCausalLM(nn.Module):
         check(lib.sd_qwen3_backward(C.byref(self._cdims), C.byref(self._cparams), C.byref(self._cgrads),
                                     input_ids.data_ptr(), _p(kv_len), cos.data_ptr(), sin.data_ptr(), acts.data_ptr(),
                                     acts.numel(), dlogits.data_ptr(), scratch.data_ptr(), sbytes, B, T, int(accumulate),
-                                    _p(dx0), cb, None, _stream()), "sd_qwen3_backward")
+                                    _p(dx0), cb, None, self._side_stream_ptr(input_ids.device), _stream()),
+              "sd_qwen3_backward")
         if red is not None:
             red.finish()
+
+    def _side_stream_ptr(self, device):
+        """Second HIP stream for the weight-gradient GEMMs (they overlap the dX chain); None disables it."""
+        if not self.overlap_dw:
+            return None
+        if self._side_stream is None:
+            self._side_stream = torch.cuda.Stream(device=device)
+        return self._side_stream.cuda_stream
 
     def forward(self, input_ids=None, attention_mask=None, labels=None, **kwargs):
         """Returns an object with ``.logits`` [B,T,V] (bf16).  ``labels`` is accepted and ignored: the
