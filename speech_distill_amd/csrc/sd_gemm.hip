@@ -245,6 +245,141 @@ __global__ __launch_bounds__(BM == 256 ? 512 : 256, (BM == 256 ? 2 : (NST * (BM 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Staggered 256x128x64 kernel (8 waves).  The L1/TA path moves 64 B/clk/CU, which for a 128x128 tile is
+// as much time as its MFMAs take, and waves of one workgroup that all issue their LDS-DMA right after
+// the same barrier and then all compute cannot overlap the two.  Here the two 4-wave halves of the
+// workgroup (one wave of each half per SIMD) run half a K-step apart: while one half is in its LOAD
+// phase (issue the DMA of tile t+2, read the fragments of tile t from LDS) the other half is in its
+// COMPUTE phase (32 MFMAs on fragments already in registers), then they swap at the next barrier.
+//   LOAD(t):    issue tile t+2 -> stage (t+2)%3 | ds_read tile t | vmcnt(6): my tile t+1 landed | lgkmcnt(0)
+//   COMPUTE(t): 32 x v_mfma_f32_16x16x32_bf16
+// Hazards (phase p = 2t for half 0, 2t+1 for half 1; a barrier separates consecutive phases):
+//   RAW  tile x is first read in phase 2x; every wave retires its own tile-x DMA with the counted vmcnt at
+//        the end of its LOAD(x-1) (phases 2x-2 / 2x-1) and then passes a barrier.
+//   WAR  stage (x-1)%3 is re-filled from phase 2x on; its last reads (tile x-1) were issued in phases
+//        2x-2 / 2x-1 and completed (lgkmcnt(0)) before those phases' closing barriers.
+template <bool TA, bool TB, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_stag_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B, bf16* C,
+                                                           const bf16* R, float* __restrict__ slabs, int M, int N, int K,
+                                                           long lda, long ldb, long ldc, long ldr, int tiles_m,
+                                                           int tiles_n, int k_tiles_per_split) {
+  constexpr int BM = 256, NW = 8, NST = 3;
+  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;  // 48 KiB
+  constexpr int LOADS = (BM + BN) / (8 * NW);                                             // 6 per wave per tile
+  __shared__ __attribute__((aligned(16))) char smem[NST * STAGE];                         // 144 KiB (epilogue: 128 KiB)
+  const int lane = lane_id();
+  const int w = wave_id_uniform();
+  const int wm = w >> 1, wn = w & 1;
+  const int half = w >> 2;  // waves 0-3 / 4-7: one of each per SIMD
+  const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int tm = tile % tiles_m, tn = tile / tiles_m;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int kt_all = (K + BK - 1) / BK;
+  const int kt0 = blockIdx.y * k_tiles_per_split;
+  const int kt1 = min(kt_all, kt0 + k_tiles_per_split);
+  const int nk = kt1 - kt0;
+  FastStage<TA, BM, NW> fa;
+  FastStage<TB, BN, NW> fb;
+  fa.init(A, lda, m0, (unsigned)((TA ? ((long)(K - 1) * lda + M) : ((long)(M - 1) * lda + K)) * 2), w, lane);
+  fb.init(B, ldb, n0, (unsigned)((TB ? ((long)(K - 1) * ldb + N) : ((long)(N - 1) * ldb + K)) * 2), w, lane);
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    fa.issue((kt0 + s) * BK, smem + s * STAGE, w);
+    fb.issue((kt0 + s) * BK, smem + s * STAGE + A_BYTES, w);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  if (half == 1) __builtin_amdgcn_s_barrier();  // second half runs one phase behind
+
+  int cur_i = 0, nxt_i = 2;
+  for (int t = 0; t < nk; ++t) {
+    // ---- LOAD(t)
+    {
+      char* nxt = smem + nxt_i * STAGE;
+      fa.issue((kt0 + t + 2) * BK, nxt, w);
+      fb.issue((kt0 + t + 2) * BK, nxt + A_BYTES, w);
+    }
+    const char* cur = smem + cur_i * STAGE;
+    bf16x8 af[2][4], bfr[2][4];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[kk][i] = load_frag<TA, BM>(cur, wm * 64 + i * 16, kk, lane);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bfr[kk][j] = load_frag<TB, BN>(cur + A_BYTES, wn * 64 + j * 16, kk, lane);
+    }
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- COMPUTE(t)
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(bfr[kk][j], af[kk][i], acc[i][j]);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    cur_i = (cur_i == 2) ? 0 : cur_i + 1;
+    nxt_i = (nxt_i == 2) ? 0 : nxt_i + 1;
+  }
+  if (half == 0) __builtin_amdgcn_s_barrier();  // re-align the halves
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  float* cs = (float*)smem;  // [256][128] fp32
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = wm * 64 + i * 16 + (lane & 15);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int cidx = wn * 16 + j * 4 + (lane >> 4);
+      *(f32x4*)(cs + m * 128 + ((cidx ^ (m & 15)) << 2)) = acc[i][j];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int q = it * 512 + threadIdx.x;
+    const int m = q >> 4, oc = q & 15;
+    const int gm = m0 + m, gn = n0 + oc * 8;
+    if (gm < M && gn < N) {
+      f32x4 lo = *(const f32x4*)(cs + m * 128 + (((2 * oc) ^ (m & 15)) << 2));
+      f32x4 hi = *(const f32x4*)(cs + m * 128 + (((2 * oc + 1) ^ (m & 15)) << 2));
+      if constexpr (EPI == 2) {
+        float* dst = slabs + ((long)blockIdx.y * M + gm) * N + gn;
+        *(f32x4*)dst = lo;
+        *(f32x4*)(dst + 4) = hi;
+      } else {
+        float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        if constexpr (EPI == 1) {
+          bf16x8 r = *(const bf16x8*)(R + (long)gm * ldr + gn);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += (float)r[e];
+        }
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
+        *(bf16x8*)(C + (long)gm * ldc + gn) = o;
+      }
+    }
+  }
+}
+
 // C = sum_s slab[s] (+ R), fixed order
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slabs, bf16* C, const bf16* R, int M,
                                                             int N, long ldc, long ldr, int splits) {
@@ -289,12 +424,15 @@ int launch(const void* A, const void* B, void* C, const void* R, float* slabs, i
   const bool fast = !g_no_fast_stage && (TA || TB || (K % BK) == 0) && span < 0x7fffffffL && span_b < 0x7fffffffL;
 #define SD_GEMM_GO(EPI)                                                                                              \
   do {                                                                                                               \
-    if (fast)                                                                                                        \
-      hipLaunchKernelGGL((gemm_bf16_kernel<BM, NST, TA, TB, EPI, true>), grid, block, 0, st, (const bf16*)A,          \
+    if constexpr (BM == 256 && NST == 9) {                                                                           \
+      hipLaunchKernelGGL((gemm_stag_kernel<TA, TB, EPI>), grid, block, 0, st, (const bf16*)A, (const bf16*)B,          \
+                         (bf16*)C, (const bf16*)R, slabs, M, N, K, lda, ldb, ldc, ldr, tiles_m, tiles_n, per);         \
+    } else if (fast)                                                                                                 \
+      hipLaunchKernelGGL((gemm_bf16_kernel<BM, (NST == 9 ? 3 : NST), TA, TB, EPI, true>), grid, block, 0, st, (const bf16*)A,          \
                          (const bf16*)B, (bf16*)C, (const bf16*)R, slabs, M, N, K, lda, ldb, ldc, ldr, tiles_m,       \
                          tiles_n, per);                                                                              \
     else                                                                                                             \
-      hipLaunchKernelGGL((gemm_bf16_kernel<BM, NST, TA, TB, EPI, false>), grid, block, 0, st, (const bf16*)A,         \
+      hipLaunchKernelGGL((gemm_bf16_kernel<BM, (NST == 9 ? 3 : NST), TA, TB, EPI, false>), grid, block, 0, st, (const bf16*)A,         \
                          (const bf16*)B, (bf16*)C, (const bf16*)R, slabs, M, N, K, lda, ldb, ldc, ldr, tiles_m,       \
                          tiles_n, per);                                                                              \
   } while (0)
@@ -338,7 +476,7 @@ int dispatch(const void* A, const void* B, void* C, const void* R, float* slabs,
   const long blocks64 = (long)((M + 63) / 64) * ((N + BN - 1) / BN) * splits;
   int bm, nst;
   if (!ta && !tb) {  // forward linear
-    if (tiles256 >= 256) { bm = 256; nst = 3; }
+    if (tiles256 >= 256) { bm = 256; nst = 9; }  // 9 = the staggered two-half kernel (gemm_stag_kernel)
     else if (tiles128 >= 256) { bm = 128; nst = 3; }
     else { bm = 64; nst = blocks64 <= 320 ? 4 : 3; }
   } else {
@@ -346,11 +484,17 @@ int dispatch(const void* A, const void* B, void* C, const void* R, float* slabs,
     nst = (bm == 64 && blocks64 <= 320) ? 3 : 2;
   }
   if (g_force_variant) { bm = g_force_variant & 0xffff; nst = g_force_variant >> 16; }
+  // the staggered kernel only has the descriptor staging path
+  bool stag_ok = !g_no_fast_stage && (ta || tb || (K % BK) == 0) &&
+                       ((long)K * (ta ? lda : 1) + (long)M * (ta ? 1 : lda)) * 2 < 0x70000000L &&
+                       ((long)K * (tb ? ldb : 1) + (long)N * (tb ? 1 : ldb)) * 2 < 0x70000000L;
   SdProfScope prof(ta ? SD_K_GEMM_TN : (tb ? SD_K_GEMM_NN : SD_K_GEMM_NT), 2.0 * M * N * K, st);
+  if (bm == 256 && nst == 9 && !stag_ok) nst = 3;
 #define SD_GO(BM_, NST_, TA_, TB_) \
   return launch<BM_, NST_, TA_, TB_>(A, B, C, R, slabs, splits, M, N, K, lda, ldb, ldc, ldr, st)
 #define SD_PICK(TA_, TB_)                                   \
   do {                                                      \
+    if (bm == 256 && nst == 9 && stag_ok) SD_GO(256, 9, TA_, TB_); \
     if (bm == 256 && nst == 2) SD_GO(256, 2, TA_, TB_);     \
     if (bm == 256) SD_GO(256, 3, TA_, TB_);                 \
     if (bm == 64 && nst == 2) SD_GO(64, 2, TA_, TB_);       \

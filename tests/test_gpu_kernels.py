@@ -73,7 +73,7 @@ def test_gemm_random(ops, M, N, K, ta, tb, res):
     check_close(f"gemm_{M}x{N}x{K}_ta{int(ta)}tb{int(tb)}r{int(res)}", got, ref, 6e-3, 3e-3)
 
 
-@pytest.mark.parametrize("bm,nst", [(256, 3), (256, 2), (128, 3), (64, 4), (64, 2), (128, 2 | 0x100), (64, 3 | 0x100)])
+@pytest.mark.parametrize("bm,nst", [(256, 9), (256, 3), (256, 2), (128, 3), (64, 4), (64, 2), (128, 2 | 0x100), (64, 3 | 0x100)])
 @pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, True)])
 def test_gemm_forced_variants_exact(ops, bm, nst, ta, tb):
     """every tile height / ring depth the heuristic can pick, on integer data (must be exact), ragged edges."""
@@ -89,6 +89,27 @@ def test_gemm_forced_variants_exact(ops, bm, nst, ta, tb):
         lib.sd_gemm_force_variant(0, 0)
     # integer sums are exact in fp32; the bf16 output rounds values above 256 (RNE), so round the reference too
     assert torch.equal(got, _gemm_ref(a, b, ta, tb).float().bfloat16().float())
+
+
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, True)])
+def test_gemm_staggered_kernel_random(ops, ta, tb):
+    """the two-half staggered 256x128 kernel (forced), long K so the 3-stage ring wraps many times; run 3x (race screen)."""
+    g = torch.Generator().manual_seed(77)
+    M, N, K = 1000, 520, 2112
+    a = bf(torch.randn((K, M) if ta else (M, K), generator=g))
+    b = bf(torch.randn((K, N) if tb else (N, K), generator=g))
+    ref = _gemm_ref(a.float(), b.float(), ta, tb)
+    lib = ops.load_lib()
+    ad, bd = to_dev(a), to_dev(b)
+    outs = []
+    for _ in range(3):
+        lib.sd_gemm_force_variant(256, 9)
+        try:
+            outs.append(ops.gemm(ad, bd, ta, tb))
+        finally:
+            lib.sd_gemm_force_variant(0, 0)
+    check_close(f"gemm_stag_ta{int(ta)}tb{int(tb)}", outs[0], ref, 6e-3, 3e-3)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
 
 
 def test_gemm_split_k(ops):
