@@ -43,6 +43,37 @@ SD_DEV void stage64(const bf16* __restrict__ g, long ld, int row0, int row_max, 
   }
 }
 
+// Same tile through a buffer descriptor (buffer_load_dwordx4 ... lds): per-lane offsets are computed once,
+// a tile advance is one scalar offset, rows past the end of the (batch, head) slice read as zeros.
+struct TileDma {
+  int voff[4];
+  long row_bytes;
+#if defined(__HIP_DEVICE_COMPILE__)
+  __amdgpu_buffer_rsrc_t rsrc;
+#endif
+  // g: first element of the slice (row 0 of this batch, this head); rows: rows in the slice
+  SD_DEV void init(const bf16* g, long ld, int rows, int w, int lane) {
+    row_bytes = ld * 2;
+#if defined(__HIP_DEVICE_COMPILE__)
+    rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)g, 0, (int)(((long)(rows - 1) * ld + D) * 2), 0x00020000);
+#endif
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int p = (w * 4 + i) * 64 + lane;
+      const int row = p >> 4, s = p & 15;
+      voff[i] = (int)(((long)row * ld + ((s ^ f_swz(row)) * 8)) * 2);
+    }
+  }
+  SD_DEV void issue(int row0, char* lds, int w) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int soff = (int)(row0 * row_bytes);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (SD_LDS void*)(lds + (w * 4 + i) * 1024), 16, voff[i], soff, 0, 0);
+#endif
+  }
+};
+
 // operand whose k index is d: lane (r = l&31, h = l>>5) holds tile[row0 + r][16*st + 8h .. +7]
 SD_DEV bf16x8 row_frag(const char* lds, int row0, int st, int lane) {
   const int row = row0 + (lane & 31);
@@ -110,19 +141,23 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
 
   const int kv_hi = min(q0 + 128, T);
   const int nkv = (kv_hi + 63) / 64;
-  stage64(kb, ldk, 0, T - 1, smem, w, lane);
-  stage64(vb, ldv, 0, T - 1, smem + TILE, w, lane);
+  TileDma kd, vd;
+  kd.init(kb, ldk, T, w, lane);
+  vd.init(vb, ldv, T, w, lane);
+  kd.issue(0, smem, w);
+  vd.issue(0, smem + TILE, w);
   __syncthreads();
   for (int t = 0; t < nkv; ++t) {
     const char* ks = smem + (t & 1) * 2 * TILE;
     const char* vs = ks + TILE;
     if (t + 1 < nkv) {
       char* nx = smem + ((t + 1) & 1) * 2 * TILE;
-      stage64(kb, ldk, (t + 1) * 64, T - 1, nx, w, lane);
-      stage64(vb, ldv, (t + 1) * 64, T - 1, nx + TILE, w, lane);
+      kd.issue((t + 1) * 64, nx, w);
+      vd.issue((t + 1) * 64, nx + TILE, w);
     }
     const int kv0 = t * 64;
     if (kv0 <= q0w + 31) {  // wave-uniform: some key of this tile is visible to some row of this wave
+      const bool need_mask = (kv0 + 63 > q0w) || (kv0 + 63 >= klen);  // wave-uniform: tile touches the diagonal / padding
       f32x16 s[2];
 #pragma unroll
       for (int kb2 = 0; kb2 < 2; ++kb2) {
@@ -132,15 +167,22 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
         for (int st = 0; st < 8; ++st) s[kb2] = mfma32(row_frag(ks, kb2 * 32, st, lane), qf[st], s[kb2]);
       }
       float mx = NEG;
+      if (need_mask) {
 #pragma unroll
-      for (int kb2 = 0; kb2 < 2; ++kb2)
+        for (int kb2 = 0; kb2 < 2; ++kb2)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int key = kv0 + kb2 * 32 + acc_row(e, h);
-          const float v = key > lim ? NEG : s[kb2][e];
-          s[kb2][e] = v;
-          mx = fmaxf(mx, v);
-        }
+          for (int e = 0; e < 16; ++e) {
+            const int key = kv0 + kb2 * 32 + acc_row(e, h);
+            const float v = key > lim ? NEG : s[kb2][e];
+            s[kb2][e] = v;
+            mx = fmaxf(mx, v);
+          }
+      } else {
+#pragma unroll
+        for (int kb2 = 0; kb2 < 2; ++kb2)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[kb2][e]);
+      }
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float mn = fmaxf(m, mx);
       const float alpha = exp2f((m - mn) * c);
@@ -251,16 +293,19 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict
 
   const int kv_hi = min(q0 + 128, T);
   const int nkv = (kv_hi + 63) / 64;
-  stage64(kb, ldk, 0, T - 1, smem, w, lane);
-  stage64(vb, ldv, 0, T - 1, smem + TILE, w, lane);
+  TileDma kd, vd;
+  kd.init(kb, ldk, T, w, lane);
+  vd.init(vb, ldv, T, w, lane);
+  kd.issue(0, smem, w);
+  vd.issue(0, smem + TILE, w);
   __syncthreads();
   for (int t = 0; t < nkv; ++t) {
     const char* ks = smem + (t & 1) * 2 * TILE;
     const char* vs = ks + TILE;
     if (t + 1 < nkv) {
       char* nx = smem + ((t + 1) & 1) * 2 * TILE;
-      stage64(kb, ldk, (t + 1) * 64, T - 1, nx, w, lane);
-      stage64(vb, ldv, (t + 1) * 64, T - 1, nx + TILE, w, lane);
+      kd.issue((t + 1) * 64, nx, w);
+      vd.issue((t + 1) * 64, nx + TILE, w);
     }
     const int kv0 = t * 64;
     if (kv0 <= q0w + 31) {
@@ -349,8 +394,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restric
     const int g = it / per_head, qt = qt0 + it % per_head;
     const int hq = hkv * G + g;
     char* dst = smem + buf * 2 * TILE;
-    stage64(Q + tok0 * ldq + hq * D, ldq, qt * 64, T - 1, dst, w, lane);
-    stage64(dO + tok0 * ldo + hq * D, ldo, qt * 64, T - 1, dst + TILE, w, lane);
+    TileDma qd, od;  // the query head changes with `it`: descriptors are rebuilt (scalar work only)
+    qd.init(Q + tok0 * ldq + hq * D, ldq, T, w, lane);
+    od.init(dO + tok0 * ldo + hq * D, ldo, T, w, lane);
+    qd.issue(qt * 64, dst, w);
+    od.issue(qt * 64, dst + TILE, w);
     if (threadIdx.x < 128) {
       const int i = threadIdx.x & 63, which = threadIdx.x >> 6;
       int qq = qt * 64 + i;
