@@ -34,7 +34,7 @@ sys.path.insert(0, ROOT)
 MFMA_PEAK_TFLOPS = 2500.0  # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
 SPEECH_LO, VOCAB = 152927, 159488
-KERNEL_NAMES = {"gemm_nt": "gemm_bf16_kernel<false,false,*>", "gemm_nn": "gemm_bf16_kernel<false,true,*>",
+KERNEL_NAMES = {"gemm_nt_stag": "gemm_stag_kernel<false, false, 0>", "gemm_nt": "gemm_bf16_kernel<*,*,false,false,*>", "gemm_nn": "gemm_bf16_kernel<false,true,*>",
                 "gemm_tn": "gemm_bf16_kernel<true,true,*>"}
 
 
@@ -92,6 +92,7 @@ def main():
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL over xGMI) | gloo (single-GPU rehearsal of the N>1 path)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--serial-teacher", action="store_true", help="teacher forward on the student's stream (no overlap)")
+    ap.add_argument("--no-overlap", action="store_true", help="single stream everywhere (clean per-kernel profiles)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -127,6 +128,9 @@ def main():
     reducer = ddp.attach(student) if world > 1 else None
     batch = synthetic_batch(args.batch, args.seq_len, rank, dev)
 
+    if args.no_overlap:
+        args.serial_teacher = True
+        student.overlap_dw = False
     side = None if args.serial_teacher else torch.cuda.Stream(device=dev)
 
     def teacher_topk():
@@ -179,7 +183,7 @@ def main():
         barrier()
         prof_dt = time.perf_counter() - tp
         prof = ops.prof_end()
-        student.overlap_dw = True
+        student.overlap_dw = not args.no_overlap
     if world > 1:
         tmax = torch.tensor([dt], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -237,6 +241,14 @@ def main():
                 res["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": ach / HBM_PEAK_GBS, "traffic": None, "kernel": dom,
                                    "avg_launch_us": 1e3 * ms / cnt, "launches_per_step": cnt / args.steps}
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if "roofline" in res and os.path.exists(pmc):
+            try:  # HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
+                t = json.load(open(pmc))
+                res["roofline"]["traffic"] = t.get(dom, t["nt_gemm"])["hbm_bytes_per_launch"]
+                res["roofline"]["traffic_source"] = t["source"]
+            except Exception:
+                pass
         if world == 1 and not args.no_cpu_baseline:
             try:
                 res["cpu_baseline"] = cpu_baseline(args.cpu_sample_tokens, min(os.cpu_count() or 1, 16))

@@ -165,7 +165,8 @@ int sd_qwen3_backward(const sd_qwen3_dims* d, const sd_qwen3_params* p, const sd
  * kinds index the arrays of sd_prof_end; work = algorithmic FLOPs (GEMM, attention) or bytes (others). */
 enum {
   SD_K_GEMM_NT = 0, SD_K_GEMM_NN, SD_K_GEMM_TN, SD_K_ATTN_FWD, SD_K_ATTN_BWD_DKV, SD_K_ATTN_BWD_DQ, SD_K_LOSS_FWD,
-  SD_K_LOSS_BWD, SD_K_TOPK, SD_K_RMSNORM, SD_K_QKROPE, SD_K_SWIGLU, SD_K_EMBED, SD_K_OPTIM, SD_K_MISC, SD_K_COUNT
+  SD_K_LOSS_BWD, SD_K_TOPK, SD_K_RMSNORM, SD_K_QKROPE, SD_K_SWIGLU, SD_K_EMBED, SD_K_OPTIM, SD_K_MISC, SD_K_GEMM_NT_STAG,
+  SD_K_COUNT
 };
 int sd_prof_begin(void);
 int sd_prof_end(double* ms, double* work, int64_t* count, int n_kinds);

@@ -39,7 +39,7 @@ class Params(C.Structure):
 
 
 KINDS = ["gemm_nt", "gemm_nn", "gemm_tn", "attn_fwd", "attn_bwd_dkv", "attn_bwd_dq", "loss_fwd", "loss_bwd", "topk",
-         "rmsnorm", "qknorm_rope", "swiglu", "embedding", "optim", "misc"]
+         "rmsnorm", "qknorm_rope", "swiglu", "embedding", "optim", "misc", "gemm_nt_stag"]
 
 STAGE_CB = C.CFUNCTYPE(None, C.c_int, C.c_void_p)
 

@@ -488,8 +488,9 @@ int dispatch(const void* A, const void* B, void* C, const void* R, float* slabs,
   bool stag_ok = !g_no_fast_stage && (ta || tb || (K % BK) == 0) &&
                        ((long)K * (ta ? lda : 1) + (long)M * (ta ? 1 : lda)) * 2 < 0x70000000L &&
                        ((long)K * (tb ? ldb : 1) + (long)N * (tb ? 1 : ldb)) * 2 < 0x70000000L;
-  SdProfScope prof(ta ? SD_K_GEMM_TN : (tb ? SD_K_GEMM_NN : SD_K_GEMM_NT), 2.0 * M * N * K, st);
   if (bm == 256 && nst == 9 && !stag_ok) nst = 3;
+  SdProfScope prof(ta ? SD_K_GEMM_TN : (tb ? SD_K_GEMM_NN : ((bm == 256 && nst == 9) ? SD_K_GEMM_NT_STAG : SD_K_GEMM_NT)),
+                   2.0 * M * N * K, st);
 #define SD_GO(BM_, NST_, TA_, TB_) \
   return launch<BM_, NST_, TA_, TB_>(A, B, C, R, slabs, splits, M, N, K, lda, ldb, ldc, ldr, st)
 #define SD_PICK(TA_, TB_)                                   \
