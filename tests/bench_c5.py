@@ -1,0 +1,67 @@
+"""BASELINE config 5 timing (not a bench.py line): teacher-only forward, batch 64 x seq_len 512, + top-K.
+Also config 4-shaped step timing (T=2048, batch 4).  Prints one JSON line each."""
+import json, os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import speech_distill_amd as sda
+from speech_distill_amd import ops
+from oracle.qwen3 import STUDENT_06B, TEACHER_17B, flops_per_token  # FLOP-count constants only
+
+dev = torch.device("cuda:0")
+
+
+def timeit(fn, n=5, w=2):
+    for _ in range(w):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n
+
+
+def init(m, seed):
+    m.flat.normal_(0.0, 0.02, generator=torch.Generator(device=dev).manual_seed(seed))
+    for p in m._params.values():
+        if p.dim() == 1:
+            p.data.fill_(1.0)
+
+
+teacher = sda.HipQwen3ForCausalLM(sda.Qwen3Dims.teacher_17b(), device=dev, init_std=0)
+init(teacher, 1)
+teacher.eval().requires_grad_(False)
+ids = torch.randint(0, 159488, (64, 512), device=dev)
+
+
+def c5():
+    with torch.no_grad():
+        ops.logsoftmax_topk(teacher(input_ids=ids).logits, 100)
+
+
+dt = timeit(c5)
+f = flops_per_token(TEACHER_17B, 512)
+print(json.dumps({"config": "C5 teacher-only B=64 T=512 + top-100", "tokens_per_s": 64 * 512 / dt, "ms": dt * 1e3,
+                  "mfma_frac": 64 * 512 / dt * f / 2.5e15}), flush=True)
+del ids
+student = sda.HipQwen3ForCausalLM(sda.Qwen3Dims.student_06b(), device=dev, init_std=0)
+init(student, 0)
+B, T = 4, 2048
+ids = torch.randint(0, 159488, (B, T), device=dev)
+labels = ids.clone()
+labels[:, : T // 4] = -100
+loss_fn = sda.DistillationLoss(2.0, 0.5, inplace_grad=True)
+
+
+def c4():
+    student.zero_grad()
+    logits = student(input_ids=ids).logits
+    with torch.no_grad():
+        tv, ti = ops.logsoftmax_topk(teacher(input_ids=ids).logits, 128)
+    loss_fn(logits, labels, teacher_top_k_v=tv, teacher_top_k_i=ti)[0].backward()
+
+
+dt = timeit(c4, n=3, w=1)
+f = 3 * flops_per_token(STUDENT_06B, T) + flops_per_token(TEACHER_17B, T)
+print(json.dumps({"config": "C4-shaped step B=4 T=2048 (1 GPU)", "tokens_per_s": B * T / dt, "ms": dt * 1e3,
+                  "mfma_frac": B * T / dt * f / 2.5e15}), flush=True)
