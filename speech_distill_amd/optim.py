@@ -1,0 +1,63 @@
+"""Fused AdamW over the model's flat bf16 parameter / gradient buffers.
+
+The reference trains pure-bf16 parameters with the HF Trainer's default AdamW, i.e. bf16 moments
+(train.py:174 loads the student in bf16, train.py:331-354 sets no ``optim``; quirk Q5), and clips the
+global gradient norm to ``max_grad_norm`` (HF trainer.py:2539).  Here one ``sd_sumsq_bf16`` launch computes
+the squared norm of the whole flat gradient and one ``sd_adamw_bf16`` launch updates all 604 M parameters
+(fp32 arithmetic in registers, one rounding of p / m / v to bf16), with the clip coefficient read from device
+memory -- no host synchronisation, ~8.5 GB of HBM traffic per step.
+
+Use with the HF Trainer:  ``DistillationTrainer(..., optimizers=(FlatAdamW(student, lr=...), None))`` and
+``max_grad_norm=0`` in TrainingArguments when ``clip`` is given here (otherwise HF clips tensor by tensor).
+Weight decay applies to matrices only (norm gains are excluded, as HF's parameter grouping does).
+"""
+import torch
+
+from . import ops
+
+
+class FlatAdamW(torch.optim.Optimizer):
+    def __init__(self, model, lr=5e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, clip=0.0):
+        self.model = model
+        params = [p for p in model.parameters() if p.requires_grad]
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, clip=clip))
+        self.exp_avg = torch.zeros_like(model.flat)
+        self.exp_avg_sq = torch.zeros_like(model.flat)
+        self._sumsq = torch.zeros(1, dtype=torch.float32, device=model.flat.device)
+        self._step = 0
+        # contiguous runs of matrices / gains in the flat layout (for decay on matrices only)
+        runs, cur = [], None
+        for name, (o, n, shape) in model._slices.items():
+            is_mat = len(shape) == 2
+            n8 = (n + 7) // 8 * 8
+            if cur is not None and cur[2] == is_mat and cur[1] == o:
+                cur[1] = o + n8
+            else:
+                cur = [o, o + n8, is_mat]
+                runs.append(cur)
+        self._runs = [(a, b, m) for a, b, m in runs]
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        g = self.param_groups[0]
+        m = self.model
+        if m.flat_grad is None:
+            return None
+        self._step += 1
+        clip = float(g["clip"])
+        ss = None
+        if clip > 0:
+            self._sumsq.zero_()
+            ops.sumsq(m.flat_grad, self._sumsq)
+            ss = self._sumsq
+        b1, b2 = g["betas"]
+        wd = float(g["weight_decay"])
+        spans = [(0, m.numel_flat, True)] if wd == 0.0 else self._runs
+        for a, b, is_mat in spans:
+            ops.adamw_(m.flat[a:b], m.flat_grad[a:b], self.exp_avg[a:b], self.exp_avg_sq[a:b], float(g["lr"]), b1, b2,
+                       g["eps"], wd if is_mat else 0.0, self._step, ss, clip)
+        return None
+
+    def grad_norm(self):
+        """Global gradient norm seen by the last step (device tensor)."""
+        return self._sumsq.sqrt()
