@@ -55,6 +55,15 @@ int64_t sd_rmsnorm_bwd_workspace_bytes(int M, int H);
 int sd_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, const void* dres, void* dx,
                    void* dw, int accumulate_dw, void* workspace, int M, int H, void* stream);
 
+/* *_bwd2: same, with the (tiny) gain-gradient reduce launched on `reduce_stream` after `event` (a hipEvent_t the
+ * caller owns); both nullable = everything on `stream`.  The caller joins the streams before reusing `workspace`. */
+int sd_rmsnorm_bwd2(const void* dy, const void* x, const void* w, const float* rstd, const void* dres, void* dx,
+                    void* dw, int accumulate_dw, void* workspace, int M, int H, void* reduce_stream, void* event,
+                    void* stream);
+int sd_qknorm_rope_bwd2(const void* dqk, const void* qkv, const void* q_gain, const void* k_gain, const void* cos_tab,
+                        const void* sin_tab, void* dqkv, void* dq_gain, void* dk_gain, int accumulate_dw, void* workspace,
+                        int M, int T, int Hq, int Hkv, float eps, void* reduce_stream, void* event, void* stream);
+
 /* ---- per-head q/k RMSNorm (head_dim 128) then rotate-half RoPE (HF:252-257, 121-170).
  * qkv [M,(Hq+2Hkv)*128] -> qk_out [M,(Hq+Hkv)*128]; cos/sin tables bf16 [T,128]; token m has position m % T. */
 int sd_qknorm_rope_fwd(const void* qkv, const void* q_gain, const void* k_gain, const void* cos_tab,
@@ -78,11 +87,17 @@ int sd_embedding_bwd(const int64_t* ids, const void* dx, void* dE, int M, int H,
 int sd_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const int32_t* kv_len, int64_t ldq,
                 int64_t ldk, int64_t ldv, int64_t ldo, int B, int T, int Hq, int Hkv, int head_dim, float scale,
                 void* stream);
-/* delta: fp32 [B,Hq,T] scratch (rowsum(dO*O)) */
+/* delta: fp32 [B,Hq,T] scratch (rowsum(dO*O)).  sd_attn_bwd2: same, with the dQ kernel launched on `side_stream`
+ * (nullable) beside the dK/dV kernel -- they only share read-only inputs; `stream` has joined when it returns. */
 int sd_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse,
                 float* delta, void* dq, void* dk, void* dv, const int32_t* kv_len, int64_t ldq, int64_t ldk, int64_t ldv,
                 int64_t ldo, int64_t lddq, int64_t lddk, int64_t lddv, int B, int T, int Hq, int Hkv, int head_dim,
                 float scale, void* stream);
+
+int sd_attn_bwd2(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse,
+                 float* delta, void* dq, void* dk, void* dv, const int32_t* kv_len, int64_t ldq, int64_t ldk, int64_t ldv,
+                 int64_t ldo, int64_t lddq, int64_t lddk, int64_t lddv, int B, int T, int Hq, int Hkv, int head_dim,
+                 float scale, void* side_stream, void* stream);
 
 /* ---- teacher log-softmax + top-K (train.py:80-91; extract_teacher_logits.py:114-129).
  * logits [rows, row_stride], first V columns used -> top_v fp16 [rows,K], top_i int32 [rows,K] sorted

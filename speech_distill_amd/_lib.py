@@ -55,6 +55,8 @@ PROTOTYPES = {
     "sd_rmsnorm_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "sd_rmsnorm_bwd_workspace_bytes": (_i64, [_i, _i]),
     "sd_rmsnorm_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _vp]),
+    "sd_rmsnorm_bwd2": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _vp, _vp, _vp]),
+    "sd_qknorm_rope_bwd2": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
     "sd_qknorm_rope_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "sd_qknorm_rope_bwd_workspace_bytes": (_i64, [_i, _i, _i]),
     "sd_qknorm_rope_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _f, _vp]),
@@ -64,6 +66,7 @@ PROTOTYPES = {
     "sd_embedding_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _vp]),
     "sd_attn_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _i, _f, _vp]),
     "sd_attn_bwd": (_i, [_vp] * 11 + [_i64] * 7 + [_i, _i, _i, _i, _i, _f, _vp]),
+    "sd_attn_bwd2": (_i, [_vp] * 11 + [_i64] * 7 + [_i, _i, _i, _i, _i, _f, _vp, _vp]),
     "sd_logsoftmax_topk": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _i, _i, _vp]),
     "sd_kdloss_stats_bytes": (_i64, [_i, _i]),
     "sd_kdloss_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _i, _vp]),

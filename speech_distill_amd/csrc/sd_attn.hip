@@ -493,29 +493,58 @@ extern "C" int sd_attn_fwd(const void* q, const void* k, const void* v, void* o,
   return 0;
 }
 
-extern "C" int sd_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse,
-                           float* delta, void* dq, void* dk, void* dv, const int32_t* kv_len, int64_t ldq, int64_t ldk,
-                           int64_t ldv, int64_t ldo, int64_t lddq, int64_t lddk, int64_t lddv, int B, int T, int Hq,
-                           int Hkv, int head_dim, float scale, void* stream) {
+namespace {
+hipEvent_t g_attn_ev[2];
+bool g_attn_ev_ready = false;
+}  // namespace
+
+extern "C" int sd_attn_bwd2(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse,
+                            float* delta, void* dq, void* dk, void* dv, const int32_t* kv_len, int64_t ldq, int64_t ldk,
+                            int64_t ldv, int64_t ldo, int64_t lddq, int64_t lddk, int64_t lddv, int B, int T, int Hq,
+                            int Hkv, int head_dim, float scale, void* side_stream, void* stream) {
   if (head_dim != D) return SD_ERR_UNSUPPORTED;
   if (int e = check_common(B, T, Hq, Hkv, ldq, ldk, ldv, ldo)) return e;
   if ((lddq | lddk | lddv) & 7) return SD_ERR_ALIGN;
-  hipStream_t st = (hipStream_t)stream;
+  hipStream_t st = (hipStream_t)stream, s2 = (hipStream_t)side_stream;
+  if (s2 && !g_attn_ev_ready) {
+    for (auto& e : g_attn_ev)
+      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return SD_ERR_WORKSPACE;
+    g_attn_ev_ready = true;
+  }
   const long total = (long)B * T * Hq;
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, st, (const bf16*)d_o,
                      (const bf16*)o, delta, ldo, T, Hq, total);
   SD_CHECK_LAUNCH();
+  hipStream_t sq = s2 ? s2 : st;  // stream of the dQ kernel
+  if (s2) {
+    if (hipEventRecord(g_attn_ev[0], st) != hipSuccess || hipStreamWaitEvent(s2, g_attn_ev[0], 0) != hipSuccess)
+      return SD_ERR_WORKSPACE;
+  }
   {
-  SdProfScope prof(SD_K_ATTN_BWD_DKV, 4.0 * B * Hq * (double)T * T * D, st);  // S, dP, dV, dK
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((T + 127) / 128, Hkv, B), dim3(256), 0, st, (const bf16*)q, (const bf16*)k,
-                     (const bf16*)v, (const bf16*)d_o, lse, (const float*)delta, (bf16*)dk, (bf16*)dv, kv_len, ldq, ldk,
-                     ldv, ldo, lddk, lddv, T, Hq, Hkv, scale);
+    SdProfScope prof2(SD_K_ATTN_BWD_DQ, 3.0 * B * Hq * (double)T * T * D, sq);  // S, dP (recomputed), dQ
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((T + 127) / 128, Hq, B), dim3(256), 0, sq, (const bf16*)q, (const bf16*)k,
+                       (const bf16*)v, (const bf16*)d_o, lse, (const float*)delta, (bf16*)dq, kv_len, ldq, ldk, ldv, ldo,
+                       lddq, T, Hq, Hkv, scale);
   }
   SD_CHECK_LAUNCH();
-  SdProfScope prof2(SD_K_ATTN_BWD_DQ, 3.0 * B * Hq * (double)T * T * D, st);  // S, dP (recomputed), dQ
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((T + 127) / 128, Hq, B), dim3(256), 0, st, (const bf16*)q, (const bf16*)k,
-                     (const bf16*)v, (const bf16*)d_o, lse, (const float*)delta, (bf16*)dq, kv_len, ldq, ldk, ldv, ldo,
-                     lddq, T, Hq, Hkv, scale);
+  {
+    SdProfScope prof(SD_K_ATTN_BWD_DKV, 4.0 * B * Hq * (double)T * T * D, st);  // S, dP, dV, dK
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((T + 127) / 128, Hkv, B), dim3(256), 0, st, (const bf16*)q,
+                       (const bf16*)k, (const bf16*)v, (const bf16*)d_o, lse, (const float*)delta, (bf16*)dk, (bf16*)dv,
+                       kv_len, ldq, ldk, ldv, ldo, lddk, lddv, T, Hq, Hkv, scale);
+  }
   SD_CHECK_LAUNCH();
+  if (s2) {
+    if (hipEventRecord(g_attn_ev[1], s2) != hipSuccess || hipStreamWaitEvent(st, g_attn_ev[1], 0) != hipSuccess)
+      return SD_ERR_WORKSPACE;
+  }
   return 0;
+}
+
+extern "C" int sd_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse,
+                           float* delta, void* dq, void* dk, void* dv, const int32_t* kv_len, int64_t ldq, int64_t ldk,
+                           int64_t ldv, int64_t ldo, int64_t lddq, int64_t lddk, int64_t lddv, int B, int T, int Hq,
+                           int Hkv, int head_dim, float scale, void* stream) {
+  return sd_attn_bwd2(q, k, v, o, d_o, lse, delta, dq, dk, dv, kv_len, ldq, ldk, ldv, ldo, lddq, lddk, lddv, B, T, Hq,
+                      Hkv, head_dim, scale, nullptr, stream);
 }

@@ -365,8 +365,11 @@ extern "C" int64_t sd_rmsnorm_bwd_workspace_bytes(int M, int H) {
   return (int64_t)nb * H * 4;
 }
 
-extern "C" int sd_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, const void* dres, void* dx,
-                              void* dw, int accumulate_dw, void* workspace, int M, int H, void* stream) {
+// reduce_stream / event (both nullable): the gain-gradient reduce only feeds the optimizer, so it may run on a
+// second stream beside the dX chain; `event` orders it after the partials.  The caller joins the streams.
+extern "C" int sd_rmsnorm_bwd2(const void* dy, const void* x, const void* w, const float* rstd, const void* dres, void* dx,
+                               void* dw, int accumulate_dw, void* workspace, int M, int H, void* reduce_stream,
+                               void* event, void* stream) {
   if (M <= 0 || (H & 7)) return SD_ERR_SHAPE;
   if (H > 4096) return SD_ERR_UNSUPPORTED;
   int nb = (M + 7) / 8 < 256 ? (M + 7) / 8 : 256;
@@ -380,10 +383,21 @@ extern "C" int sd_rmsnorm_bwd(const void* dy, const void* x, const void* w, cons
   if (nch <= 1) SD_RMS_BWD(1); else if (nch == 2) SD_RMS_BWD(2); else if (nch <= 4) SD_RMS_BWD(4); else SD_RMS_BWD(8);
 #undef SD_RMS_BWD
   SD_CHECK_LAUNCH();
-  hipLaunchKernelGGL(colsum_reduce_kernel, dim3((H + 31) / 32), dim3(256), 0, ST, (const float*)workspace, (bf16*)dw,
+  hipStream_t rs = ST;
+  if (reduce_stream && event) {
+    rs = (hipStream_t)reduce_stream;
+    if (hipEventRecord((hipEvent_t)event, ST) != hipSuccess || hipStreamWaitEvent(rs, (hipEvent_t)event, 0) != hipSuccess)
+      return SD_ERR_WORKSPACE;
+  }
+  hipLaunchKernelGGL(colsum_reduce_kernel, dim3((H + 31) / 32), dim3(256), 0, rs, (const float*)workspace, (bf16*)dw,
                      nb, H, H, accumulate_dw);
   SD_CHECK_LAUNCH();
   return 0;
+}
+
+extern "C" int sd_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, const void* dres, void* dx,
+                              void* dw, int accumulate_dw, void* workspace, int M, int H, void* stream) {
+  return sd_rmsnorm_bwd2(dy, x, w, rstd, dres, dx, dw, accumulate_dw, workspace, M, H, nullptr, nullptr, stream);
 }
 
 extern "C" int sd_qknorm_rope_fwd(const void* qkv, const void* q_gain, const void* k_gain, const void* cos_tab,
@@ -411,10 +425,10 @@ extern "C" int64_t sd_qknorm_rope_bwd_workspace_bytes(int M, int Hq, int Hkv) {
   return (int64_t)qk_bwd_blocks((long)M * (Hq + Hkv), &ipb) * 256 * 4;
 }
 
-extern "C" int sd_qknorm_rope_bwd(const void* dqk, const void* qkv, const void* q_gain, const void* k_gain,
-                                  const void* cos_tab, const void* sin_tab, void* dqkv, void* dq_gain, void* dk_gain,
-                                  int accumulate_dw, void* workspace, int M, int T, int Hq, int Hkv, float eps,
-                                  void* stream) {
+extern "C" int sd_qknorm_rope_bwd2(const void* dqk, const void* qkv, const void* q_gain, const void* k_gain,
+                                   const void* cos_tab, const void* sin_tab, void* dqkv, void* dq_gain, void* dk_gain,
+                                   int accumulate_dw, void* workspace, int M, int T, int Hq, int Hkv, float eps,
+                                   void* reduce_stream, void* event, void* stream) {
   if (M <= 0 || T <= 0 || (M % T)) return SD_ERR_SHAPE;
   int ipb;
   const int nb = qk_bwd_blocks((long)M * (Hq + Hkv), &ipb);
@@ -424,13 +438,27 @@ extern "C" int sd_qknorm_rope_bwd(const void* dqk, const void* qkv, const void* 
                      (float*)workspace, M, T, Hq, Hkv, eps, ipb);
   SD_CHECK_LAUNCH();
   // partial layout [nb][256]: columns 0..127 -> q gain, 128..255 -> k gain
-  hipLaunchKernelGGL(colsum_reduce_kernel, dim3(4), dim3(256), 0, ST, (const float*)workspace, (bf16*)dq_gain, nb, 128,
+  hipStream_t rs = ST;
+  if (reduce_stream && event) {
+    rs = (hipStream_t)reduce_stream;
+    if (hipEventRecord((hipEvent_t)event, ST) != hipSuccess || hipStreamWaitEvent(rs, (hipEvent_t)event, 0) != hipSuccess)
+      return SD_ERR_WORKSPACE;
+  }
+  hipLaunchKernelGGL(colsum_reduce_kernel, dim3(4), dim3(256), 0, rs, (const float*)workspace, (bf16*)dq_gain, nb, 128,
                      256, accumulate_dw);
   SD_CHECK_LAUNCH();
-  hipLaunchKernelGGL(colsum_reduce_kernel, dim3(4), dim3(256), 0, ST, (const float*)workspace + 128, (bf16*)dk_gain,
+  hipLaunchKernelGGL(colsum_reduce_kernel, dim3(4), dim3(256), 0, rs, (const float*)workspace + 128, (bf16*)dk_gain,
                      nb, 128, 256, accumulate_dw);
   SD_CHECK_LAUNCH();
   return 0;
+}
+
+extern "C" int sd_qknorm_rope_bwd(const void* dqk, const void* qkv, const void* q_gain, const void* k_gain,
+                                  const void* cos_tab, const void* sin_tab, void* dqkv, void* dq_gain, void* dk_gain,
+                                  int accumulate_dw, void* workspace, int M, int T, int Hq, int Hkv, float eps,
+                                  void* stream) {
+  return sd_qknorm_rope_bwd2(dqk, qkv, q_gain, k_gain, cos_tab, sin_tab, dqkv, dq_gain, dk_gain, accumulate_dw, workspace, M,
+                             T, Hq, Hkv, eps, nullptr, nullptr, stream);
 }
 
 extern "C" int sd_swiglu_fwd(const void* gate_up, void* act, int M, int I, void* stream) {

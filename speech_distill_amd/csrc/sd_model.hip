@@ -5,6 +5,7 @@
 // as the reference calls it at train.py:54 (student, with grad) and train.py:60-69 (teacher, no grad).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "../../include/sd_hip.h"
 
 namespace {
@@ -47,7 +48,7 @@ LayerActs carve(const Sizes& s, char* p) {
 }
 
 struct BwdScratch {
-  char *dx_a, *dx_b, *dxn, *dqkv, *dqk, *dao, *delta, *dgu, *dact, *ws_norm, *ws_qk, *ws_splitk;
+  char *dx_a, *dx_b, *dxn, *dqkv, *dqk, *dao, *delta, *dgu, *dact, *ws_norm, *ws_norm2, *ws_qk, *ws_splitk;
   int64_t total, splitk_bytes;
   BwdScratch(const Sizes& s, char* p) {
     char* p0 = p;
@@ -61,6 +62,7 @@ struct BwdScratch {
     dgu = p; p += s.gu;
     dact = p; p += s.act;
     ws_norm = p; p += al(sd_rmsnorm_bwd_workspace_bytes(s.M, s.h));
+    ws_norm2 = p; p += al(sd_rmsnorm_bwd_workspace_bytes(s.M, s.h));
     ws_qk = p; p += al(sd_qknorm_rope_bwd_workspace_bytes(s.M, s.Hq, s.Hkv));
     splitk_bytes = sd_gemm_splitk_workspace_bytes(s.M, s.h, s.V);
     for (int k : {s.QKV, 2 * s.I, s.QD, s.I}) {
@@ -75,7 +77,7 @@ struct BwdScratch {
 #define RUN(call) do { int e__ = (call); if (e__) return e__; } while (0)
 
 // Events ordering the optional side stream against the main one (created once, timing disabled).
-hipEvent_t g_ev[8];
+hipEvent_t g_ev[12];
 bool g_ev_ready = false;
 bool ensure_events() {
   if (g_ev_ready) return true;
@@ -161,6 +163,8 @@ extern "C" int sd_qwen3_backward(const sd_qwen3_dims* d, const sd_qwen3_params* 
   char* xn_f = rstd_f + s.rstd;
   const int acc = accumulate ? 1 : 0;
 #define ACC(ptr) (acc ? (const void*)(ptr) : (const void*)nullptr)
+  // A/B switch for measurements: SD_OVERLAP_MASK bit0 lm_head dW, bit1 gain reduces, bit2 attention dQ (default all on)
+  static const int ovl = getenv("SD_OVERLAP_MASK") ? atoi(getenv("SD_OVERLAP_MASK")) : 7;
   hipStream_t s1 = (hipStream_t)stream, s2 = (hipStream_t)side_stream;
   if (s2 && !ensure_events()) return SD_ERR_WORKSPACE;
   void* wstream = s2 ? side_stream : stream;  // where weight-gradient GEMMs go
@@ -169,13 +173,16 @@ extern "C" int sd_qwen3_backward(const sd_qwen3_dims* d, const sd_qwen3_params* 
 #define JOIN() do { if (s2) { if (hipEventRecord(g_ev[7], s2) != hipSuccess || hipStreamWaitEvent(s1, g_ev[7], 0) != hipSuccess) return SD_ERR_WORKSPACE; } } while (0)
 
   // lm_head: dxn = dlogits . W ; dW (+)= dlogits^T . xn_f
+  SIGNAL(0);  // dlogits (produced on `stream` by the caller) is final: lm_head dW runs beside lm_head dX
+  RUN(sd_gemm_bf16(dlogits, xn_f, g->lm_head, ACC(g->lm_head), s.V, s.h, s.M, s.V, s.h, s.h, s.h, 1, 1,
+                   (ovl & 1) ? wstream : stream));
   RUN(sd_gemm_bf16_splitk(dlogits, p->lm_head, b.dxn, nullptr, s.M, s.h, s.V, s.V, s.h, s.h, 0, 0, 1, b.ws_splitk,
                           b.splitk_bytes, stream));
-  RUN(sd_gemm_bf16(dlogits, xn_f, g->lm_head, ACC(g->lm_head), s.V, s.h, s.M, s.V, s.h, s.h, s.h, 1, 1, stream));
   if (g->embed != g->lm_head && !acc)
     if (hipMemsetAsync(g->embed, 0, (size_t)s.V * s.h * 2, (hipStream_t)stream) != hipSuccess) return SD_ERR_WORKSPACE;
   RUN(sd_rmsnorm_bwd(b.dxn, x_last, p->final_norm, (const float*)rstd_f, nullptr, b.dx_a, g->final_norm, acc, b.ws_norm,
                      s.M, s.h, stream));
+  JOIN();
   if (on_grads_ready) on_grads_ready(SD_STAGE_HEAD, cb_user);
   for (int l = s.L - 1; l >= 0; --l) {
     LayerActs a = carve(s, base + (int64_t)l * s.per_layer());
@@ -190,17 +197,17 @@ extern "C" int sd_qwen3_backward(const sd_qwen3_dims* d, const sd_qwen3_params* 
     RUN(sd_gemm_bf16_splitk(b.dgu, w.wgu, b.dxn, nullptr, s.M, s.h, 2 * s.I, 2 * s.I, s.h, s.h, 0, 0, 1, b.ws_splitk,
                             b.splitk_bytes, stream));
     RUN(sd_gemm_bf16(b.dgu, a.xn2, gw.wgu, ACC(gw.wgu), 2 * s.I, s.h, s.M, 2 * s.I, s.h, s.h, s.h, 1, 1, wstream));
-    RUN(sd_rmsnorm_bwd(b.dxn, a.x_mid, w.ln2, (const float*)a.rstd2, b.dx_a, b.dx_b, gw.ln2, acc, b.ws_norm, s.M, s.h,
-                       stream));
+    RUN(sd_rmsnorm_bwd2(b.dxn, a.x_mid, w.ln2, (const float*)a.rstd2, b.dx_a, b.dx_b, gw.ln2, acc, b.ws_norm2, s.M, s.h,
+                        (ovl & 2) ? side_stream : nullptr, s2 ? (void*)g_ev[8] : nullptr, stream));
     SIGNAL(2);  // dx_b final
     // attention
     RUN(sd_gemm_bf16(b.dx_b, w.wo, b.dao, nullptr, s.M, s.QD, s.h, s.h, s.QD, s.QD, 0, 0, 1, stream));
     RUN(sd_gemm_bf16(b.dx_b, a.ao, gw.wo, ACC(gw.wo), s.h, s.QD, s.M, s.h, s.QD, s.QD, s.QD, 1, 1, wstream));
-    RUN(sd_attn_bwd(a.qk, a.qk + (int64_t)s.QD * 2, a.qkv + (int64_t)(s.QD + s.KD) * 2, a.ao, b.dao, (const float*)a.lse,
+    RUN(sd_attn_bwd2(a.qk, a.qk + (int64_t)s.QD * 2, a.qkv + (int64_t)(s.QD + s.KD) * 2, a.ao, b.dao, (const float*)a.lse,
                     (float*)b.delta, b.dqk, b.dqk + (int64_t)s.QD * 2, b.dqkv + (int64_t)(s.QD + s.KD) * 2, kv_len, s.QK,
-                    s.QK, s.QKV, s.QD, s.QK, s.QK, s.QKV, B, T, s.Hq, s.Hkv, 128, scale, stream));
-    RUN(sd_qknorm_rope_bwd(b.dqk, a.qkv, w.q_gain, w.k_gain, cos_tab, sin_tab, b.dqkv, gw.q_gain, gw.k_gain, acc, b.ws_qk,
-                           s.M, T, s.Hq, s.Hkv, d->eps, stream));
+                    s.QK, s.QKV, s.QD, s.QK, s.QK, s.QKV, B, T, s.Hq, s.Hkv, 128, scale, (ovl & 4) ? side_stream : nullptr, stream));
+    RUN(sd_qknorm_rope_bwd2(b.dqk, a.qkv, w.q_gain, w.k_gain, cos_tab, sin_tab, b.dqkv, gw.q_gain, gw.k_gain, acc, b.ws_qk,
+                            s.M, T, s.Hq, s.Hkv, d->eps, (ovl & 2) ? side_stream : nullptr, s2 ? (void*)g_ev[9] : nullptr, stream));
     SIGNAL(3);  // dqkv final
     RUN(sd_gemm_bf16(b.dqkv, a.xn1, gw.wqkv, ACC(gw.wqkv), s.QKV, s.h, s.M, s.QKV, s.h, s.h, s.h, 1, 1, wstream));
     RUN(sd_gemm_bf16_splitk(b.dqkv, w.wqkv, b.dxn, nullptr, s.M, s.h, s.QKV, s.QKV, s.h, s.h, 0, 0, 1, b.ws_splitk,
