@@ -245,8 +245,9 @@ def main():
         if "roofline" in res and os.path.exists(pmc):
             try:  # HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
                 t = json.load(open(pmc))
-                res["roofline"]["traffic"] = t.get(dom, t["nt_gemm"])["hbm_bytes_per_launch"]
-                res["roofline"]["traffic_source"] = t["source"]
+                e = t.get(dom, t["nt_gemm"])
+                res["roofline"]["traffic"] = e["hbm_bytes_per_launch"]
+                res["roofline"]["traffic_source"] = "profiles/r01_pmc_traffic.json (" + e["kernel"] + "): " + t["method"]
             except Exception:
                 pass
         if world == 1 and not args.no_cpu_baseline:
