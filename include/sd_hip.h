@@ -48,6 +48,12 @@ int sd_gemm_bf16_splitk(const void* A, const void* B, void* C, const void* R, in
                         int64_t ldb, int64_t ldc, int64_t ldr, int trans_a, int trans_b, void* workspace,
                         int64_t workspace_bytes, void* stream);
 
+/* same, but the slabs are left un-reduced for a consumer that sums them (sd_rmsnorm_bwd_slabs); *nsplit_out = number
+ * of slabs written to workspace ([nsplit][M][N] fp32), or 1 when no split was planned and bf16 C was written. */
+int sd_gemm_bf16_splitk_partial(const void* A, const void* B, void* C, int M, int N, int K, int64_t lda, int64_t ldb,
+                                int64_t ldc, int trans_a, int trans_b, void* workspace, int64_t workspace_bytes,
+                                int* nsplit_out, void* stream);
+
 /* ---- RMSNorm (HF:59-64).  rstd (fp32 [M], nullable in fwd) is saved for backward. */
 int sd_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int M, int H, float eps, void* stream);
 int64_t sd_rmsnorm_bwd_workspace_bytes(int M, int H);
@@ -60,6 +66,10 @@ int sd_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rs
 int sd_rmsnorm_bwd2(const void* dy, const void* x, const void* w, const float* rstd, const void* dres, void* dx,
                     void* dw, int accumulate_dw, void* workspace, int M, int H, void* reduce_stream, void* event,
                     void* stream);
+/* dy given as nsplit fp32 slabs [nsplit][M][H] (un-reduced split-K output), summed in slab order inside the kernel */
+int sd_rmsnorm_bwd_slabs(const float* dy_slabs, int nsplit, const void* x, const void* w, const float* rstd,
+                         const void* dres, void* dx, void* dw, int accumulate_dw, void* workspace, int M, int H,
+                         void* reduce_stream, void* event, void* stream);
 int sd_qknorm_rope_bwd2(const void* dqk, const void* qkv, const void* q_gain, const void* k_gain, const void* cos_tab,
                         const void* sin_tab, void* dqkv, void* dq_gain, void* dk_gain, int accumulate_dw, void* workspace,
                         int M, int T, int Hq, int Hkv, float eps, void* reduce_stream, void* event, void* stream);

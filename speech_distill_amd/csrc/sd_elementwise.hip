@@ -70,8 +70,11 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const bf16* __restrict
 // Gain gradient: every lane owns fixed columns and keeps their sums over this block's rows in
 // registers; the 4 waves are combined through LDS in a fixed order (deterministic), one partial
 // row per block, summed by colsum_reduce_kernel.
-template <int NCH>
-__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ x,
+// SLABS: dy is given as `nsplit` fp32 slabs [nsplit][M][H] (the un-reduced output of a split-K GEMM), summed here
+// in slab order -- the separate split-K reduce pass and its bf16 rounding disappear.
+template <int NCH, bool SLABS>
+__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16* __restrict__ dy, const float* __restrict__ dy_slabs,
+                                                          int nsplit, const bf16* __restrict__ x,
                                                           const bf16* __restrict__ w, const float* __restrict__ rstd,
                                                           const bf16* dres, bf16* dx, float* __restrict__ dw_part,
                                                           int M, int H, int rows_per_block) {
@@ -90,18 +93,30 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16* __restrict
   }
   for (int row = r0 + wv; row < r1; row += 4) {
     const bf16* xr = x + (long)row * H;
-    const bf16* dyr = dy + (long)row * H;
+    const bf16* dyr = SLABS ? nullptr : dy + (long)row * H;
     const float rs = rstd[row];
-    bf16x8 xv[NCH], dv[NCH];
+    bf16x8 xv[NCH];
+    float dv[NCH][8];
     float dot = 0.f;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       const int c = lane * 8 + i * 512;
       if (c < H) {
         xv[i] = *(const bf16x8*)(xr + c);
-        dv[i] = *(const bf16x8*)(dyr + c);
+        if constexpr (SLABS) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) dot += (float)dv[i][e] * wf[i][e] * (float)xv[i][e] * rs;
+          for (int e = 0; e < 8; ++e) dv[i][e] = 0.f;
+          for (int sp = 0; sp < nsplit; ++sp) {
+            const float* ps = dy_slabs + ((long)sp * M + row) * H + c;
+            const f32x4 a = *(const f32x4*)ps, b = *(const f32x4*)(ps + 4);
+            dv[i][0] += a[0]; dv[i][1] += a[1]; dv[i][2] += a[2]; dv[i][3] += a[3];
+            dv[i][4] += b[0]; dv[i][5] += b[1]; dv[i][6] += b[2]; dv[i][7] += b[3];
+          }
+        } else {
+          unpack8(*(const bf16x8*)(dyr + c), dv[i]);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dot += dv[i][e] * wf[i][e] * (float)xv[i][e] * rs;
       }
     }
     dot = wave_sum(dot) / (float)H;
@@ -113,7 +128,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16* __restrict
         if (dres) unpack8(*(const bf16x8*)(dres + (long)row * H + c), o);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const float xh = (float)xv[i][e] * rs, d = (float)dv[i][e];
+          const float xh = (float)xv[i][e] * rs, d = dv[i][e];
           const float v = rs * (d * wf[i][e] - xh * dot);
           o[e] = dres ? o[e] + v : v;
           acc[i][e] += d * xh;
@@ -367,18 +382,26 @@ extern "C" int64_t sd_rmsnorm_bwd_workspace_bytes(int M, int H) {
 
 // reduce_stream / event (both nullable): the gain-gradient reduce only feeds the optimizer, so it may run on a
 // second stream beside the dX chain; `event` orders it after the partials.  The caller joins the streams.
-extern "C" int sd_rmsnorm_bwd2(const void* dy, const void* x, const void* w, const float* rstd, const void* dres, void* dx,
-                               void* dw, int accumulate_dw, void* workspace, int M, int H, void* reduce_stream,
-                               void* event, void* stream) {
+static int rmsnorm_bwd_any(const void* dy, const float* dy_slabs, int nsplit, const void* x, const void* w,
+                           const float* rstd, const void* dres, void* dx, void* dw, int accumulate_dw, void* workspace,
+                           int M, int H, void* reduce_stream, void* event, void* stream) {
   if (M <= 0 || (H & 7)) return SD_ERR_SHAPE;
   if (H > 4096) return SD_ERR_UNSUPPORTED;
   int nb = (M + 7) / 8 < 256 ? (M + 7) / 8 : 256;
   const int rpb = (M + nb - 1) / nb;
   nb = (M + rpb - 1) / rpb;
-  SdProfScope prof(SD_K_RMSNORM, (dres ? 8.0 : 6.0) * M * H, ST);
-#define SD_RMS_BWD(N) hipLaunchKernelGGL(rmsnorm_bwd_kernel<N>, dim3(nb), dim3(256), 4 * H * 4, ST, (const bf16*)dy, \
-                                         (const bf16*)x, (const bf16*)w, rstd, (const bf16*)dres, (bf16*)dx,       \
-                                         (float*)workspace, M, H, rpb)
+  SdProfScope prof(SD_K_RMSNORM, ((dres ? 8.0 : 6.0) + (dy_slabs ? 4.0 * nsplit - 2.0 : 0.0)) * M * H, ST);
+#define SD_RMS_BWD(N)                                                                                                  \
+  do {                                                                                                                 \
+    if (dy_slabs)                                                                                                      \
+      hipLaunchKernelGGL((rmsnorm_bwd_kernel<N, true>), dim3(nb), dim3(256), 4 * H * 4, ST, (const bf16*)nullptr,       \
+                         dy_slabs, nsplit, (const bf16*)x, (const bf16*)w, rstd, (const bf16*)dres, (bf16*)dx,           \
+                         (float*)workspace, M, H, rpb);                                                                \
+    else                                                                                                               \
+      hipLaunchKernelGGL((rmsnorm_bwd_kernel<N, false>), dim3(nb), dim3(256), 4 * H * 4, ST, (const bf16*)dy,           \
+                         (const float*)nullptr, 0, (const bf16*)x, (const bf16*)w, rstd, (const bf16*)dres, (bf16*)dx,   \
+                         (float*)workspace, M, H, rpb);                                                                \
+  } while (0)
   const int nch = (H + 511) / 512;
   if (nch <= 1) SD_RMS_BWD(1); else if (nch == 2) SD_RMS_BWD(2); else if (nch <= 4) SD_RMS_BWD(4); else SD_RMS_BWD(8);
 #undef SD_RMS_BWD
@@ -393,6 +416,21 @@ extern "C" int sd_rmsnorm_bwd2(const void* dy, const void* x, const void* w, con
                      nb, H, H, accumulate_dw);
   SD_CHECK_LAUNCH();
   return 0;
+}
+
+extern "C" int sd_rmsnorm_bwd2(const void* dy, const void* x, const void* w, const float* rstd, const void* dres, void* dx,
+                               void* dw, int accumulate_dw, void* workspace, int M, int H, void* reduce_stream,
+                               void* event, void* stream) {
+  return rmsnorm_bwd_any(dy, nullptr, 0, x, w, rstd, dres, dx, dw, accumulate_dw, workspace, M, H, reduce_stream, event,
+                         stream);
+}
+
+extern "C" int sd_rmsnorm_bwd_slabs(const float* dy_slabs, int nsplit, const void* x, const void* w, const float* rstd,
+                                    const void* dres, void* dx, void* dw, int accumulate_dw, void* workspace, int M, int H,
+                                    void* reduce_stream, void* event, void* stream) {
+  if (!dy_slabs || nsplit < 1 || ((uintptr_t)dy_slabs & 15)) return SD_ERR_SHAPE;
+  return rmsnorm_bwd_any(nullptr, dy_slabs, nsplit, x, w, rstd, dres, dx, dw, accumulate_dw, workspace, M, H, reduce_stream,
+                         event, stream);
 }
 
 extern "C" int sd_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, const void* dres, void* dx,

@@ -407,6 +407,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 }
 
 bool g_no_fast_stage = false;  // tests / A-B measurements: force the checked staging path
+thread_local bool g_skip_reduce = false;  // set by sd_gemm_bf16_splitk_partial around its dispatch
 
 template <int BM, int NST, bool TA, bool TB>
 int launch(const void* A, const void* B, void* C, const void* R, float* slabs, int splits, int M, int N, int K, long lda,
@@ -441,7 +442,7 @@ int launch(const void* A, const void* B, void* C, const void* R, float* slabs, i
   else SD_GEMM_GO(0);
 #undef SD_GEMM_GO
   SD_CHECK_LAUNCH();
-  if (splits > 1) {
+  if (splits > 1 && !g_skip_reduce) {
     const long n8 = (long)M * N / 8;
     const int nb = (int)((n8 + 255) / 256 < 2048 ? (n8 + 255) / 256 : 2048);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(nb), dim3(256), 0, st, (const float*)slabs, (bf16*)C, (const bf16*)R, M,
@@ -550,4 +551,21 @@ extern "C" int sd_gemm_bf16_splitk(const void* A, const void* B, void* C, const 
   if (s > 1 && (workspace == nullptr || workspace_bytes < (int64_t)s * M * N * 4)) s = 1;
   if (s > 1 && ((uintptr_t)workspace & 15)) return SD_ERR_ALIGN;
   return dispatch(A, B, C, R, (float*)workspace, s, M, N, K, lda, ldb, ldc, ldr, trans_a, trans_b, (hipStream_t)stream);
+}
+
+// Split-K GEMM that leaves its `*nsplit_out` fp32 slabs [nsplit][M][N] un-reduced in `workspace` for a consumer that
+// sums them itself (sd_rmsnorm_bwd_slabs).  When the plan is a single slice it writes bf16 C as usual and reports 1.
+extern "C" int sd_gemm_bf16_splitk_partial(const void* A, const void* B, void* C, int M, int N, int K, int64_t lda,
+                                           int64_t ldb, int64_t ldc, int trans_a, int trans_b, void* workspace,
+                                           int64_t workspace_bytes, int* nsplit_out, void* stream) {
+  if (int e = check_args(A, B, C, nullptr, M, N, K, lda, ldb, ldc, 0, trans_a, trans_b)) return e;
+  int s = sd_gemm_splitk_plan(M, N, K);
+  if (s > 1 && (workspace == nullptr || workspace_bytes < (int64_t)s * M * N * 4)) s = 1;
+  if (s > 1 && ((uintptr_t)workspace & 15)) return SD_ERR_ALIGN;
+  *nsplit_out = s;
+  g_skip_reduce = true;
+  const int rc = dispatch(A, B, C, nullptr, (float*)workspace, s, M, N, K, lda, ldb, ldc, 0, trans_a, trans_b,
+                          (hipStream_t)stream);
+  g_skip_reduce = false;
+  return rc;
 }

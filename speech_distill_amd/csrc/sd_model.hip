@@ -176,12 +176,19 @@ extern "C" int sd_qwen3_backward(const sd_qwen3_dims* d, const sd_qwen3_params* 
   SIGNAL(0);  // dlogits (produced on `stream` by the caller) is final: lm_head dW runs beside lm_head dX
   RUN(sd_gemm_bf16(dlogits, xn_f, g->lm_head, ACC(g->lm_head), s.V, s.h, s.M, s.V, s.h, s.h, s.h, 1, 1,
                    (ovl & 1) ? wstream : stream));
-  RUN(sd_gemm_bf16_splitk(dlogits, p->lm_head, b.dxn, nullptr, s.M, s.h, s.V, s.V, s.h, s.h, 0, 0, 1, b.ws_splitk,
-                          b.splitk_bytes, stream));
+  int nsp = 1;
+  RUN(sd_gemm_bf16_splitk_partial(dlogits, p->lm_head, b.dxn, s.M, s.h, s.V, s.V, s.h, s.h, 0, 1, b.ws_splitk,
+                                  b.splitk_bytes, &nsp, stream));
   if (g->embed != g->lm_head && !acc)
     if (hipMemsetAsync(g->embed, 0, (size_t)s.V * s.h * 2, (hipStream_t)stream) != hipSuccess) return SD_ERR_WORKSPACE;
-  RUN(sd_rmsnorm_bwd(b.dxn, x_last, p->final_norm, (const float*)rstd_f, nullptr, b.dx_a, g->final_norm, acc, b.ws_norm,
-                     s.M, s.h, stream));
+  // the norm backward sums the split-K slabs itself (no separate reduce pass)
+#define NORM_BWD(X, W, RSTD, DRES, DX, DW, WS, RS, EV)                                                                   \
+  do {                                                                                                                   \
+    if (nsp > 1) RUN(sd_rmsnorm_bwd_slabs((const float*)b.ws_splitk, nsp, X, W, RSTD, DRES, DX, DW, acc, WS, s.M, s.h, RS, \
+                                          EV, stream));                                                                  \
+    else RUN(sd_rmsnorm_bwd2(b.dxn, X, W, RSTD, DRES, DX, DW, acc, WS, s.M, s.h, RS, EV, stream));                         \
+  } while (0)
+  NORM_BWD(x_last, p->final_norm, (const float*)rstd_f, nullptr, b.dx_a, g->final_norm, b.ws_norm, nullptr, nullptr);
   JOIN();
   if (on_grads_ready) on_grads_ready(SD_STAGE_HEAD, cb_user);
   for (int l = s.L - 1; l >= 0; --l) {
@@ -194,11 +201,11 @@ extern "C" int sd_qwen3_backward(const sd_qwen3_dims* d, const sd_qwen3_params* 
     RUN(sd_gemm_bf16(b.dx_a, w.wdown, b.dact, nullptr, s.M, s.I, s.h, s.h, s.I, s.I, 0, 0, 1, stream));
     RUN(sd_swiglu_bwd(b.dact, a.gu, b.dgu, s.M, s.I, stream));
     SIGNAL(1);  // dgu final
-    RUN(sd_gemm_bf16_splitk(b.dgu, w.wgu, b.dxn, nullptr, s.M, s.h, 2 * s.I, 2 * s.I, s.h, s.h, 0, 0, 1, b.ws_splitk,
-                            b.splitk_bytes, stream));
+    RUN(sd_gemm_bf16_splitk_partial(b.dgu, w.wgu, b.dxn, s.M, s.h, 2 * s.I, 2 * s.I, s.h, s.h, 0, 1, b.ws_splitk,
+                                    b.splitk_bytes, &nsp, stream));
     RUN(sd_gemm_bf16(b.dgu, a.xn2, gw.wgu, ACC(gw.wgu), 2 * s.I, s.h, s.M, 2 * s.I, s.h, s.h, s.h, 1, 1, wstream));
-    RUN(sd_rmsnorm_bwd2(b.dxn, a.x_mid, w.ln2, (const float*)a.rstd2, b.dx_a, b.dx_b, gw.ln2, acc, b.ws_norm2, s.M, s.h,
-                        (ovl & 2) ? side_stream : nullptr, s2 ? (void*)g_ev[8] : nullptr, stream));
+    NORM_BWD(a.x_mid, w.ln2, (const float*)a.rstd2, b.dx_a, b.dx_b, gw.ln2, b.ws_norm2, (ovl & 2) ? side_stream : nullptr,
+             s2 ? (void*)g_ev[8] : nullptr);
     SIGNAL(2);  // dx_b final
     // attention
     RUN(sd_gemm_bf16(b.dx_b, w.wo, b.dao, nullptr, s.M, s.QD, s.h, s.h, s.QD, s.QD, 0, 0, 1, stream));
@@ -210,16 +217,17 @@ extern "C" int sd_qwen3_backward(const sd_qwen3_dims* d, const sd_qwen3_params* 
                             s.M, T, s.Hq, s.Hkv, d->eps, (ovl & 2) ? side_stream : nullptr, s2 ? (void*)g_ev[9] : nullptr, stream));
     SIGNAL(3);  // dqkv final
     RUN(sd_gemm_bf16(b.dqkv, a.xn1, gw.wqkv, ACC(gw.wqkv), s.QKV, s.h, s.M, s.QKV, s.h, s.h, s.h, 1, 1, wstream));
-    RUN(sd_gemm_bf16_splitk(b.dqkv, w.wqkv, b.dxn, nullptr, s.M, s.h, s.QKV, s.QKV, s.h, s.h, 0, 0, 1, b.ws_splitk,
-                            b.splitk_bytes, stream));
+    RUN(sd_gemm_bf16_splitk_partial(b.dqkv, w.wqkv, b.dxn, s.M, s.h, s.QKV, s.QKV, s.h, s.h, 0, 1, b.ws_splitk,
+                                    b.splitk_bytes, &nsp, stream));
     JOIN();  // the layer's dW GEMMs are done before dx_a / dgu / dx_b / dqkv are overwritten and before the callback
-    RUN(sd_rmsnorm_bwd(b.dxn, a.x_in, w.ln1, (const float*)a.rstd1, b.dx_b, (l == 0 && dx0_out) ? dx0_out : b.dx_a,
-                       gw.ln1, acc, b.ws_norm, s.M, s.h, stream));
+    NORM_BWD(a.x_in, w.ln1, (const float*)a.rstd1, b.dx_b, (l == 0 && dx0_out) ? dx0_out : b.dx_a, gw.ln1, b.ws_norm,
+             nullptr, nullptr);
     if (on_grads_ready) on_grads_ready(l, cb_user);
   }
   if (!dx0_out) RUN(sd_embedding_bwd(ids, b.dx_a, g->embed, s.M, s.h, s.V, 1.0f, stream));
   if (on_grads_ready) on_grads_ready(SD_STAGE_EMBED, cb_user);
 #undef ACC
+#undef NORM_BWD
 #undef SIGNAL
 #undef JOIN
   return 0;

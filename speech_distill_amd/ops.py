@@ -262,3 +262,28 @@ def prof_end():
     ms, work, cnt = (C.c_double * n)(), (C.c_double * n)(), (C.c_int64 * n)()
     check(load_lib().sd_prof_end(ms, work, cnt, n), "sd_prof_end")
     return {KINDS[i]: (ms[i], work[i], cnt[i]) for i in range(n)}
+
+
+def rmsnorm_bwd_from_splitk(a, b_kn, x, w, rstd, dres=None):
+    """dx, dw of RMSNorm where dy = a @ b_kn is produced by a split-K GEMM whose fp32 slabs the norm kernel sums
+    itself (sd_gemm_bf16_splitk_partial + sd_rmsnorm_bwd_slabs).  Returns (dx, dw, nsplit)."""
+    import ctypes as C
+    lib = load_lib()
+    M, K = a.shape
+    N = b_kn.shape[1]
+    nb = max(lib.sd_gemm_splitk_workspace_bytes(M, N, K), 16)
+    ws = torch.empty(nb, dtype=torch.uint8, device=a.device)
+    dy = torch.empty(M, N, dtype=torch.bfloat16, device=a.device)
+    nsp = C.c_int(0)
+    check(lib.sd_gemm_bf16_splitk_partial(a.data_ptr(), b_kn.data_ptr(), dy.data_ptr(), M, N, K, a.stride(0), b_kn.stride(0),
+                                          N, 0, 1, ws.data_ptr(), nb, C.byref(nsp), _stream()), "sd_gemm_bf16_splitk_partial")
+    wsn = torch.empty(lib.sd_rmsnorm_bwd_workspace_bytes(M, N), dtype=torch.uint8, device=a.device)
+    dx, dw = torch.empty_like(x), torch.zeros_like(w)
+    if nsp.value > 1:
+        check(lib.sd_rmsnorm_bwd_slabs(ws.data_ptr(), nsp.value, x.data_ptr(), w.data_ptr(), rstd.data_ptr(), _p(dres),
+                                       dx.data_ptr(), dw.data_ptr(), 0, wsn.data_ptr(), M, N, 0, 0, _stream()),
+              "sd_rmsnorm_bwd_slabs")
+    else:
+        check(lib.sd_rmsnorm_bwd2(dy.data_ptr(), x.data_ptr(), w.data_ptr(), rstd.data_ptr(), _p(dres), dx.data_ptr(),
+                                  dw.data_ptr(), 0, wsn.data_ptr(), M, N, 0, 0, _stream()), "sd_rmsnorm_bwd2")
+    return dx, dw, nsp.value

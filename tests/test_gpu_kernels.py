@@ -151,6 +151,23 @@ def test_rmsnorm_fwd_bwd(ops, O, M, H):
     check_close(f"rmsnorm_bwd_dw_{M}x{H}", dw, wr.grad, 1.2e-2, 4e-3)
 
 
+def test_rmsnorm_bwd_consumes_splitk_slabs(ops):
+    """dX GEMM (split-K, fp32 slabs left un-reduced) -> RMSNorm backward summing the slabs itself."""
+    g = torch.Generator().manual_seed(21)
+    M, H, K = 192, 1024, 4096
+    a, bkn = bf(torch.randn(M, K, generator=g) * 0.05), bf(torch.randn(K, H, generator=g))
+    x, w = bf(torch.randn(M, H, generator=g) * 2), bf(1 + 0.2 * torch.randn(H, generator=g))
+    dres = bf(torch.randn(M, H, generator=g))
+    _, rstd = ops.rmsnorm_fwd(to_dev(x), to_dev(w))
+    dx, dw, nsp = ops.rmsnorm_bwd_from_splitk(to_dev(a), to_dev(bkn), to_dev(x), to_dev(w), rstd, to_dev(dres))
+    assert nsp > 1
+    dy = a.double() @ bkn.double()
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    (wr * (xr * torch.rsqrt(xr.pow(2).mean(-1, keepdim=True) + 1e-6)) * dy).sum().backward()
+    check_close("rmsnorm_bwd_slabs_dx", dx, xr.grad + dres.double(), 1.2e-2, 3e-3)
+    check_close("rmsnorm_bwd_slabs_dw", dw, wr.grad, 1.2e-2, 4e-3)
+
+
 @pytest.mark.parametrize("B,T,Hq,Hkv", [(2, 24, 4, 2), (1, 130, 2, 1)])
 def test_qknorm_rope_fwd_bwd(ops, O, B, T, Hq, Hkv):
     g = torch.Generator().manual_seed(T)
