@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
                                                        float* __restrict__ LSE, const int* __restrict__ kv_len, long ldq,
                                                        long ldk, long ldv, long ldo, int T, int Hq, int Hkv,
                                                        float scale) {
-  __shared__ __attribute__((aligned(16))) char smem[4 * TILE];  // 2 stages x (K,V)
+  __shared__ __attribute__((aligned(16))) char smem[6 * TILE];  // 3 stages x (K,V)
   const int lane = lane_id(), w = wave_id_uniform();
   const int qt = gridDim.x - 1 - blockIdx.x;  // heaviest (latest) query tiles first
   const int hq = blockIdx.y, b = blockIdx.z;
@@ -144,17 +144,27 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
   TileDma kd, vd;
   kd.init(kb, ldk, T, w, lane);
   vd.init(vb, ldv, T, w, lane);
+  // 3-stage K/V ring: tile t+2 is issued while tile t is used; the wait for tile t is a counted vmcnt that
+  // leaves tile t+1 in flight across the raw barrier.  Tiles past the end are still issued (rows beyond the
+  // slice read as zeros), which keeps the count uniform.
   kd.issue(0, smem, w);
   vd.issue(0, smem + TILE, w);
-  __syncthreads();
+  kd.issue(64, smem + 2 * TILE, w);
+  vd.issue(64, smem + 3 * TILE, w);
+  int cur_i = 0, nxt_i = 2;
   for (int t = 0; t < nkv; ++t) {
-    const char* ks = smem + (t & 1) * 2 * TILE;
-    const char* vs = ks + TILE;
-    if (t + 1 < nkv) {
-      char* nx = smem + ((t + 1) & 1) * 2 * TILE;
-      kd.issue((t + 1) * 64, nx, w);
-      vd.issue((t + 1) * 64, nx + TILE, w);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    {
+      char* nx = smem + nxt_i * 2 * TILE;
+      kd.issue((t + 2) * 64, nx, w);
+      vd.issue((t + 2) * 64, nx + TILE, w);
     }
+    const char* ks = smem + cur_i * 2 * TILE;
+    const char* vs = ks + TILE;
+    cur_i = (cur_i == 2) ? 0 : cur_i + 1;
+    nxt_i = (nxt_i == 2) ? 0 : nxt_i + 1;
     const int kv0 = t * 64;
     if (kv0 <= q0w + 31) {  // wave-uniform: some key of this tile is visible to some row of this wave
       const bool need_mask = (kv0 + 63 > q0w) || (kv0 + 63 >= klen);  // wave-uniform: tile touches the diagonal / padding
@@ -210,8 +220,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
           for (int db = 0; db < 4; ++db) o[db] = mfma32(tr_frag(vs, kb2 * 32 + 16 * ss, db, lane), pf, o[db]);
         }
     }
-    __syncthreads();
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the tail tiles before the workgroup retires
   l += __shfl_xor(l, 32, 64);
   const float inv = 1.f / l;
   if (q < T) {
@@ -260,7 +270,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict
                                                           bf16* __restrict__ dQ, const int* __restrict__ kv_len, long ldq,
                                                           long ldk, long ldv, long ldo, long lddq, int T, int Hq, int Hkv,
                                                           float scale) {
-  __shared__ __attribute__((aligned(16))) char smem[4 * TILE];
+  __shared__ __attribute__((aligned(16))) char smem[6 * TILE];
   const int lane = lane_id(), w = wave_id_uniform();
   const int qt = gridDim.x - 1 - blockIdx.x;
   const int hq = blockIdx.y, b = blockIdx.z;
@@ -298,15 +308,22 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict
   vd.init(vb, ldv, T, w, lane);
   kd.issue(0, smem, w);
   vd.issue(0, smem + TILE, w);
-  __syncthreads();
+  kd.issue(64, smem + 2 * TILE, w);
+  vd.issue(64, smem + 3 * TILE, w);
+  int cur_i = 0, nxt_i = 2;
   for (int t = 0; t < nkv; ++t) {
-    const char* ks = smem + (t & 1) * 2 * TILE;
-    const char* vs = ks + TILE;
-    if (t + 1 < nkv) {
-      char* nx = smem + ((t + 1) & 1) * 2 * TILE;
-      kd.issue((t + 1) * 64, nx, w);
-      vd.issue((t + 1) * 64, nx + TILE, w);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    {
+      char* nx = smem + nxt_i * 2 * TILE;
+      kd.issue((t + 2) * 64, nx, w);
+      vd.issue((t + 2) * 64, nx + TILE, w);
     }
+    const char* ks = smem + cur_i * 2 * TILE;
+    const char* vs = ks + TILE;
+    cur_i = (cur_i == 2) ? 0 : cur_i + 1;
+    nxt_i = (nxt_i == 2) ? 0 : nxt_i + 1;
     const int kv0 = t * 64;
     if (kv0 <= q0w + 31) {
 #pragma unroll
@@ -333,8 +350,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict
         }
       }
     }
-    __syncthreads();
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (q < T) {
     bf16* orow = dQ + (tok0 + q) * lddq + hq * D;
 #pragma unroll
@@ -359,8 +376,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restric
                                                            const int* __restrict__ kv_len, long ldq, long ldk, long ldv,
                                                            long ldo, long lddk, long lddv, int T, int Hq, int Hkv,
                                                            float scale) {
-  __shared__ __attribute__((aligned(16))) char smem[4 * TILE];  // 2 stages x (Q, dO)
-  __shared__ __attribute__((aligned(16))) float stat[2][2][64];  // [stage][lse2|delta][q row]
+  __shared__ __attribute__((aligned(16))) char smem[6 * TILE];  // 3 stages x (Q, dO)
+  __shared__ __attribute__((aligned(16))) float stat[3][2][64];  // [stage][lse2|delta][q row]
   const int lane = lane_id(), w = wave_id_uniform();
   const int hkv = blockIdx.y, b = blockIdx.z;
   const int G = Hq / Hkv;
@@ -390,30 +407,49 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restric
   const int nqt = (T + 63) / 64;
   const int per_head = nqt - qt0;
   const int nit = G * per_head;
-  auto stage_it = [&](int it, int buf) {
-    const int g = it / per_head, qt = qt0 + it % per_head;
+  // 3-stage (Q, dO) ring, counted vmcnt + raw barrier (see attn_fwd_kernel).  The LSE / delta values of a
+  // stage are loaded into a register BEFORE that stage's DMA is issued, so the compiler's wait for them
+  // (ahead of the ds_write) does not also drain the DMA that was just started.
+  const int st_i = threadIdx.x & 63, st_which = (threadIdx.x >> 6) & 1;
+  auto stage_it = [&](int it, int buf) -> float {
+    const bool real = it < nit;
+    const int itc = real ? it : nit - 1;
+    const int g = itc / per_head, qt = real ? qt0 + itc % per_head : nqt + 1;  // past-the-end tile: rows read as zeros
     const int hq = hkv * G + g;
     char* dst = smem + buf * 2 * TILE;
+    float sv = 0.f;
+    if (threadIdx.x < 128) {
+      int qq = qt * 64 + st_i;
+      qq = qq < T ? qq : T - 1;
+      const long o = ((long)b * Hq + hq) * T + qq;
+      sv = st_which ? delta[o] : LSE[o] * LOG2E;
+    }
     TileDma qd, od;  // the query head changes with `it`: descriptors are rebuilt (scalar work only)
     qd.init(Q + tok0 * ldq + hq * D, ldq, T, w, lane);
     od.init(dO + tok0 * ldo + hq * D, ldo, T, w, lane);
     qd.issue(qt * 64, dst, w);
     od.issue(qt * 64, dst + TILE, w);
-    if (threadIdx.x < 128) {
-      const int i = threadIdx.x & 63, which = threadIdx.x >> 6;
-      int qq = qt * 64 + i;
-      qq = qq < T ? qq : T - 1;
-      const long o = ((long)b * Hq + hq) * T + qq;
-      stat[buf][which][i] = which ? delta[o] : LSE[o] * LOG2E;
-    }
+    return sv;  // written to stat[buf] one iteration later, so that its wait never drains the DMA issued above
   };
-  stage_it(0, 0);
-  __syncthreads();
+  {
+    const float sv0 = stage_it(0, 0);
+    if (threadIdx.x < 128) stat[0][st_which][st_i] = sv0;
+  }
+  float pend_sv = stage_it(1, 1);
+  int pend_buf = 1;
+  int cur_i = 0, nxt_i = 2;
   for (int it = 0; it < nit; ++it) {
-    const int buf = it & 1;
+    asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (threadIdx.x < 128) stat[pend_buf][st_which][st_i] = pend_sv;
+    pend_sv = stage_it(it + 2, nxt_i);
+    pend_buf = nxt_i;
+    const int buf = cur_i;
     const char* qs = smem + buf * 2 * TILE;
     const char* dos = qs + TILE;
-    if (it + 1 < nit) stage_it(it + 1, buf ^ 1);
+    cur_i = (cur_i == 2) ? 0 : cur_i + 1;
+    nxt_i = (nxt_i == 2) ? 0 : nxt_i + 1;
     const int qbase = (qt0 + it % per_head) * 64;
 #pragma unroll
     for (int qb2 = 0; qb2 < 2; ++qb2) {
@@ -451,8 +487,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restric
         }
       }
     }
-    __syncthreads();
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (key < T) {
     bf16* kr = dK + (tok0 + key) * lddk + hkv * D;
     bf16* vr = dV + (tok0 + key) * lddv + hkv * D;
