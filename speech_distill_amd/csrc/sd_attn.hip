@@ -94,6 +94,26 @@ SD_DEV bf16x8 tr_frag(const char* lds, int rb, int db, int lane) {
   return cat8(lo, hi);
 }
 
+// tr_frag for db = 0..3 at once, as asm reads (see lds_tr16_pair_asm: the builtin makes hipcc drain the K/V
+// prefetch before every transposed read) followed by one lgkmcnt(0).
+SD_DEV void tr_frag4(const char* lds, int rb, int lane, bf16x8 (&out)[4]) {
+  const int gi = lane >> 4, i = lane & 15, q4 = i >> 2, pp = i & 3;
+  const int rA = rb + 4 * (gi >> 1) + q4, rB = rA + 8;
+  const int sA = f_swz(rA), sB = f_swz(rB);
+  const unsigned base = lds_addr(lds) + 8 * (pp & 1);
+  const unsigned aA = base + rA * 256, aB = base + rB * 256;
+  const int chl = (gi & 1) * 2 + (pp >> 1);
+  sd_u64 raw[8];
+#pragma unroll
+  for (int db = 0; db < 4; ++db) {
+    const int ch = db * 4 + chl;
+    lds_tr16_pair_asm(raw[2 * db], raw[2 * db + 1], aA + ((ch ^ sA) << 4), aB + ((ch ^ sB) << 4));
+  }
+  lds_tr_wait8(raw);
+#pragma unroll
+  for (int db = 0; db < 4; ++db) out[db] = cat8_u64(raw[2 * db], raw[2 * db + 1]);
+}
+
 SD_DEV bf16x8 acc_frag(const f32x16& p, int s) {
   bf16x8 r;
 #pragma unroll
@@ -216,8 +236,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
 #pragma unroll
         for (int ss = 0; ss < 2; ++ss) {
           const bf16x8 pf = acc_frag(s[kb2], ss);
+          bf16x8 vt[4];
+          tr_frag4(vs, kb2 * 32 + 16 * ss, lane, vt);
 #pragma unroll
-          for (int db = 0; db < 4; ++db) o[db] = mfma32(tr_frag(vs, kb2 * 32 + 16 * ss, db, lane), pf, o[db]);
+          for (int db = 0; db < 4; ++db) o[db] = mfma32(vt[db], pf, o[db]);
         }
     }
   }
@@ -345,8 +367,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict
 #pragma unroll
         for (int ss = 0; ss < 2; ++ss) {
           const bf16x8 df = acc_frag(s, ss);
+          bf16x8 kt4[4];
+          tr_frag4(ks, kb2 * 32 + 16 * ss, lane, kt4);
 #pragma unroll
-          for (int db = 0; db < 4; ++db) acc[db] = mfma32(tr_frag(ks, kb2 * 32 + 16 * ss, db, lane), df, acc[db]);
+          for (int db = 0; db < 4; ++db) acc[db] = mfma32(kt4[db], df, acc[db]);
         }
       }
     }
@@ -480,10 +504,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restric
 #pragma unroll
       for (int ss = 0; ss < 2; ++ss) {
         const bf16x8 pf = acc_frag(s, ss), df = acc_frag(ds, ss);
+        bf16x8 dot4[4], qt4[4];
+        tr_frag4(dos, qb2 * 32 + 16 * ss, lane, dot4);
+        tr_frag4(qs, qb2 * 32 + 16 * ss, lane, qt4);
 #pragma unroll
         for (int db = 0; db < 4; ++db) {
-          dv[db] = mfma32(tr_frag(dos, qb2 * 32 + 16 * ss, db, lane), pf, dv[db]);  // dV^T += dO^T P
-          dk[db] = mfma32(tr_frag(qs, qb2 * 32 + 16 * ss, db, lane), df, dk[db]);   // dK^T += Q^T dS
+          dv[db] = mfma32(dot4[db], pf, dv[db]);  // dV^T += dO^T P
+          dk[db] = mfma32(qt4[db], df, dk[db]);   // dK^T += Q^T dS
         }
       }
     }

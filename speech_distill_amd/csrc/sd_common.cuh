@@ -85,6 +85,29 @@ SD_DEV bf16x4 lds_tr16(const void* lds_addr) {
   s16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4i16((SD_LDS s16x4*)lds_addr);
   return __builtin_bit_cast(bf16x4, t);
 }
+// The same read as inline asm.  hipcc treats the ds_read_tr builtin as "may alias the LDS-DMA in flight" and
+// drains vmcnt(0) in front of it, which serialises the global->LDS prefetch with the compute of every K-step;
+// an asm read WITHOUT a "memory" clobber is invisible to that pass (with the clobber it drains just the same).  In exchange nothing waits for it: the caller issues a batch, then
+// lds_tr_wait*() (s_waitcnt lgkmcnt(0) naming every destination, so no consumer or copy can move above it).
+typedef unsigned long long sd_u64;
+SD_DEV unsigned lds_addr(const void* p) { return (unsigned)(uintptr_t)(SD_LDS const char*)p; }
+SD_DEV void lds_tr16_pair_asm(sd_u64& lo, sd_u64& hi, unsigned a0, unsigned a1) {
+  asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %3" : "=&v"(lo), "=&v"(hi) : "v"(a0), "v"(a1));
+}
+SD_DEV bf16x8 cat8_u64(sd_u64 lo, sd_u64 hi) {
+  typedef __attribute__((ext_vector_type(2))) sd_u64 u64x2;
+  u64x2 v = {lo, hi};
+  return __builtin_bit_cast(bf16x8, v);
+}
+#define SD_TRW2(a) "+v"(a[0]), "+v"(a[1])
+SD_DEV void lds_tr_wait4(sd_u64 (&a)[4]) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]));
+}
+SD_DEV void lds_tr_wait8(sd_u64 (&a)[8]) {
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]));
+}
+
 SD_DEV bf16x8 cat8(bf16x4 a, bf16x4 b) {
   bf16x8 r;
   r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = a[3];

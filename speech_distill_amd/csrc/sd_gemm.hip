@@ -119,6 +119,27 @@ SD_DEV bf16x8 load_frag(const char* lds_tile, int row16_base, int kk, int lane) 
   }
 }
 
+// Transposed-operand fragments for one kk step, NF fragments (16 rows each from row_base): issues the 2*NF
+// ds_read_b64_tr_b16 as asm (see lds_tr16_pair_asm) into raw[], waits once, then packs.
+template <int ROWS, int NF>
+SD_DEV void load_frags_tr(const char* lds_tile, int row_base, int kk, int lane, bf16x8 (&out)[NF]) {
+  static_assert(NF == 2 || NF == 4, "NF");
+  sd_u64 raw[2 * NF];
+  const int g = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3;
+  const int k0 = kk * 32 + 8 * g + q, k1 = k0 + 4;
+  const unsigned base = lds_addr(lds_tile);
+  const unsigned r0 = base + k0 * (ROWS * 2) + 8 * pp, r1 = base + k1 * (ROWS * 2) + 8 * pp;
+  const int s0 = swz_t<ROWS>(k0), s1 = swz_t<ROWS>(k1);
+#pragma unroll
+  for (int f = 0; f < NF; ++f) {
+    const int ch = (row_base >> 4) + f;
+    lds_tr16_pair_asm(raw[2 * f], raw[2 * f + 1], r0 + ((ch ^ s0) << 5), r1 + ((ch ^ s1) << 5));
+  }
+  if constexpr (NF == 2) lds_tr_wait4(raw); else lds_tr_wait8(raw);
+#pragma unroll
+  for (int f = 0; f < NF; ++f) out[f] = cat8_u64(raw[2 * f], raw[2 * f + 1]);
+}
+
 // EPI: 0 = bf16 out, 1 = bf16 out + residual, 2 = fp32 slab out (split-K)
 // NST-deep LDS ring: tile t+NST-1 is issued while tile t is computed; the wait for tile t is a COUNTED
 // s_waitcnt vmcnt that leaves the NST-2 younger tiles in flight across the (raw) barrier.  Tiles past
@@ -190,10 +211,18 @@ __global__ __launch_bounds__(BM == 256 ? 512 : 256, (BM == 256 ? 2 : (NST * (BM 
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       bf16x8 af[MT], bfr[4];
+      if constexpr (TA) {
+        load_frags_tr<BM, MT>(cur, wm * WROWS, kk, lane, af);
+      } else {
 #pragma unroll
-      for (int i = 0; i < MT; ++i) af[i] = load_frag<TA, BM>(cur, wm * WROWS + i * 16, kk, lane);
+        for (int i = 0; i < MT; ++i) af[i] = load_frag<TA, BM>(cur, wm * WROWS + i * 16, kk, lane);
+      }
+      if constexpr (TB) {
+        load_frags_tr<BN, 4>(cur + A_BYTES, wn * 64, kk, lane, bfr);
+      } else {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) bfr[j] = load_frag<TB, BN>(cur + A_BYTES, wn * 64 + j * 16, kk, lane);
+        for (int j = 0; j < 4; ++j) bfr[j] = load_frag<TB, BN>(cur + A_BYTES, wn * 64 + j * 16, kk, lane);
+      }
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -312,10 +341,18 @@ __global__ __launch_bounds__(512, 2) void gemm_stag_kernel(const bf16* __restric
     bf16x8 af[2][4], bfr[2][4];
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
+      if constexpr (TA) {
+        load_frags_tr<BM, 4>(cur, wm * 64, kk, lane, af[kk]);
+      } else {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) af[kk][i] = load_frag<TA, BM>(cur, wm * 64 + i * 16, kk, lane);
+        for (int i = 0; i < 4; ++i) af[kk][i] = load_frag<TA, BM>(cur, wm * 64 + i * 16, kk, lane);
+      }
+      if constexpr (TB) {
+        load_frags_tr<BN, 4>(cur + A_BYTES, wn * 64, kk, lane, bfr[kk]);
+      } else {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) bfr[kk][j] = load_frag<TB, BN>(cur + A_BYTES, wn * 64 + j * 16, kk, lane);
+        for (int j = 0; j < 4; ++j) bfr[kk][j] = load_frag<TB, BN>(cur + A_BYTES, wn * 64 + j * 16, kk, lane);
+      }
     }
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -480,9 +517,14 @@ int dispatch(const void* A, const void* B, void* C, const void* R, float* slabs,
     if (tiles256 >= 256) { bm = 256; nst = 9; }  // 9 = the staggered two-half kernel (gemm_stag_kernel)
     else if (tiles128 >= 256) { bm = 128; nst = 3; }
     else { bm = 64; nst = blocks64 <= 320 ? 4 : 3; }
-  } else {
-    bm = tiles128 < 448 ? 64 : 128;
-    nst = (bm == 64 && blocks64 <= 320) ? 3 : 2;
+  } else if (!ta) {  // NN: dX = dY . W (weights cold)
+    if (splits > 1 || tiles256 >= 192) { bm = 256; nst = 9; }
+    else if (tiles128 >= 256) { bm = 128; nst = 3; }
+    else { bm = 64; nst = 3; }
+  } else {  // TN: dW = dY^T . X (two warm activations)
+    if (tiles256 >= 1024) { bm = 256; nst = 9; }
+    else if (tiles128 >= 320) { bm = 128; nst = 2; }
+    else { bm = 64; nst = blocks64 <= 320 ? 3 : 2; }
   }
   if (g_force_variant) { bm = g_force_variant & 0xffff; nst = g_force_variant >> 16; }
   // the staggered kernel only has the descriptor staging path
@@ -529,12 +571,13 @@ extern "C" void sd_gemm_force_variant(int bm, int nst) {
 }
 
 extern "C" int sd_gemm_splitk_plan(int M, int N, int K) {
-  const long tiles = (long)((M + 63) / 64) * ((N + BN - 1) / BN);
+  // Measured (tests/bench_shapes.py --tune --cold): with prefetch that really overlaps, K <= 6144 is best unsplit;
+  // only the lm_head-class contraction (K = vocabulary) is split, onto 256x128 staggered tiles.
+  const long tiles = (long)((M + 255) / 256) * ((N + BN - 1) / BN);
   const int kt = (K + BK - 1) / BK;
-  if (tiles >= 512 || kt < 64) return 1;  // measured: pays for K >= 4096 with <= 256 tiles of 64x128, hurts below
-  int s = (int)((768 + tiles - 1) / tiles);
+  if (tiles >= 256 || kt < 256) return 1;
+  int s = (int)((512 + tiles - 1) / tiles);
   if (s > 8) s = 8;
-  if (s > kt / 16) s = kt / 16;
   return s < 1 ? 1 : s;
 }
 

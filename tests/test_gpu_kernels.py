@@ -115,7 +115,7 @@ def test_gemm_staggered_kernel_random(ops, ta, tb):
 def test_gemm_split_k(ops):
     """few tiles + long K -> fp32 slabs + fixed-order reduce (the lm_head dX shape class)."""
     g = torch.Generator().manual_seed(6)
-    M, N, K = 256, 128, 8192
+    M, N, K = 256, 128, 32768
     a, b = bf(torch.randn(M, K, generator=g)), bf(torch.randn(K, N, generator=g))
     r = bf(torch.randn(M, N, generator=g))
     lib = ops.load_lib()
@@ -154,7 +154,7 @@ def test_rmsnorm_fwd_bwd(ops, O, M, H):
 def test_rmsnorm_bwd_consumes_splitk_slabs(ops):
     """dX GEMM (split-K, fp32 slabs left un-reduced) -> RMSNorm backward summing the slabs itself."""
     g = torch.Generator().manual_seed(21)
-    M, H, K = 192, 1024, 4096
+    M, H, K = 192, 1024, 16384
     a, bkn = bf(torch.randn(M, K, generator=g) * 0.05), bf(torch.randn(K, H, generator=g))
     x, w = bf(torch.randn(M, H, generator=g) * 2), bf(1 + 0.2 * torch.randn(H, generator=g))
     dres = bf(torch.randn(M, H, generator=g))
