@@ -215,14 +215,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
       }
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float mn = fmaxf(m, mx);
-      const float alpha = exp2f((m - mn) * c);
+      const float alpha = __builtin_amdgcn_exp2f((m - mn) * c);
       m = mn;
       float rs = 0.f;
 #pragma unroll
       for (int kb2 = 0; kb2 < 2; ++kb2)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-          const float p = exp2f((s[kb2][e] - mn) * c);
+          const float p = __builtin_amdgcn_exp2f((s[kb2][e] - mn) * c);
           s[kb2][e] = p;
           rs += p;
         }
@@ -361,7 +361,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int key = kv0 + kb2 * 32 + acc_row(e, h);
-          const float p = key > lim ? 0.f : exp2f(s[e] * c - lse2);
+          const float p = key > lim ? 0.f : __builtin_amdgcn_exp2f(s[e] * c - lse2);
           s[e] = p * (dp[e] - dl);  // dS^T (without the d^-1/2 factor)
         }
 #pragma unroll
@@ -496,7 +496,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restric
         for (int e = 0; e < 4; ++e) {
           const int qq = qb0 + 8 * g4 + 4 * h + e;
           const bool vis = key_ok && key <= qq && qq < T;
-          const float p = vis ? exp2f(s[4 * g4 + e] * c - l2[e]) : 0.f;
+          const float p = vis ? __builtin_amdgcn_exp2f(s[4 * g4 + e] * c - l2[e]) : 0.f;
           s[4 * g4 + e] = p;
           ds[4 * g4 + e] = p * (dp[4 * g4 + e] - dl[e]);
         }
