@@ -29,22 +29,9 @@ constexpr float LOG2E = 1.4426950408889634f;
 
 SD_DEV int f_swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
 
-// Stage rows [row0, row0+64) of a [*, 128]-column slice (row stride ld) into a 16 KiB LDS tile.
-// Rows are clamped to [0, row_max] (finite data; masked later).
-SD_DEV void stage64(const bf16* __restrict__ g, long ld, int row0, int row_max, char* lds, int w, int lane) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int p = (w * 4 + i) * 64 + lane;
-    const int row = p >> 4, s = p & 15;
-    const int ch = s ^ f_swz(row);
-    int gr = row0 + row;
-    gr = gr > row_max ? row_max : gr;
-    glds16(g + (long)gr * ld + ch * 8, lds + (w * 4 + i) * 1024);
-  }
-}
-
-// Same tile through a buffer descriptor (buffer_load_dwordx4 ... lds): per-lane offsets are computed once,
-// a tile advance is one scalar offset, rows past the end of the (batch, head) slice read as zeros.
+// Stage 64 rows of a [*, 128]-column slice (row stride ld) into a 16 KiB LDS tile through a buffer descriptor
+// (buffer_load_dwordx4 ... lds): per-lane offsets are computed once, a tile advance is one scalar offset, rows
+// past the end of the (batch, head) slice read as zeros (they are masked later).
 struct TileDma {
   int voff[4];
   long row_bytes;
@@ -81,20 +68,10 @@ SD_DEV bf16x8 row_frag(const char* lds, int row0, int st, int lane) {
   return *(const bf16x8*)(lds + row * 256 + ((ch ^ f_swz(row)) << 4));
 }
 
-// operand whose k index is the tile row: lane (r = l&31 -> column db*32 + r, h = l>>5) holds
-// tile[rb + 8(j>>2) + 4h + (j&3)][db*32 + r], j = 0..7  (rb = first row of this 16-row k-step).
-// This is exactly the k order of accumulator registers 8s..8s+7 used as the other operand.
-SD_DEV bf16x8 tr_frag(const char* lds, int rb, int db, int lane) {
-  const int gi = lane >> 4, i = lane & 15, q4 = i >> 2, pp = i & 3;
-  const int rA = rb + 4 * (gi >> 1) + q4, rB = rA + 8;
-  const int ch = db * 4 + (gi & 1) * 2 + (pp >> 1);
-  const int sub = 8 * (pp & 1);
-  bf16x4 lo = lds_tr16(lds + rA * 256 + ((ch ^ f_swz(rA)) << 4) + sub);
-  bf16x4 hi = lds_tr16(lds + rB * 256 + ((ch ^ f_swz(rB)) << 4) + sub);
-  return cat8(lo, hi);
-}
-
-// tr_frag for db = 0..3 at once, as asm reads (see lds_tr16_pair_asm: the builtin makes hipcc drain the K/V
+// Operand whose k index is the tile ROW (transposed read): lane (r = l&31 -> column db*32 + r, h = l>>5) holds
+// tile[rb + 8(j>>2) + 4h + (j&3)][db*32 + r], j = 0..7  (rb = first row of this 16-row k-step) -- exactly the k
+// order of accumulator registers 8s..8s+7 used as the other operand.  Two ds_read_b64_tr_b16 per fragment.
+// The fragments for db = 0..3 at once, as asm reads (see lds_tr16_pair_asm: the builtin makes hipcc drain the K/V
 // prefetch before every transposed read) followed by one lgkmcnt(0).
 SD_DEV void tr_frag4(const char* lds, int rb, int lane, bf16x8 (&out)[4]) {
   const int gi = lane >> 4, i = lane & 15, q4 = i >> 2, pp = i & 3;

@@ -78,14 +78,10 @@ SD_DEV void glds16(const void* gsrc, void* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const SD_GLB void*)gsrc, (SD_LDS void*)lds_wave_base, 16, 0, 0);
 }
 
-// ds_read_b64_tr_b16: per 16-lane group, reads a 4-row x 16-column block of 16-bit elements and
-// hands lane i of the group column i of the 4 rows.  Lane 4q+p of the group supplies the address
-// of row q, columns 4p..4p+3 (8 bytes, 8-byte aligned).  EXEC must be all ones.
-SD_DEV bf16x4 lds_tr16(const void* lds_addr) {
-  s16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4i16((SD_LDS s16x4*)lds_addr);
-  return __builtin_bit_cast(bf16x4, t);
-}
-// The same read as inline asm.  hipcc treats the ds_read_tr builtin as "may alias the LDS-DMA in flight" and
+// ds_read_b64_tr_b16: per 16-lane group, reads a 4-row x 16-column block of 16-bit elements and hands lane i of
+// the group column i of the 4 rows.  Lane 4q+p of the group supplies the address of row q, columns 4p..4p+3
+// (8 bytes, 8-byte aligned).  EXEC must be all ones.  Issued as inline asm:
+// hipcc treats the ds_read_tr builtin as "may alias the LDS-DMA in flight" and
 // drains vmcnt(0) in front of it, which serialises the global->LDS prefetch with the compute of every K-step;
 // an asm read WITHOUT a "memory" clobber is invisible to that pass (with the clobber it drains just the same).  In exchange nothing waits for it: the caller issues a batch, then
 // lds_tr_wait*() (s_waitcnt lgkmcnt(0) naming every destination, so no consumer or copy can move above it).
@@ -99,20 +95,12 @@ SD_DEV bf16x8 cat8_u64(sd_u64 lo, sd_u64 hi) {
   u64x2 v = {lo, hi};
   return __builtin_bit_cast(bf16x8, v);
 }
-#define SD_TRW2(a) "+v"(a[0]), "+v"(a[1])
 SD_DEV void lds_tr_wait4(sd_u64 (&a)[4]) {
   asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]));
 }
 SD_DEV void lds_tr_wait8(sd_u64 (&a)[8]) {
   asm volatile("s_waitcnt lgkmcnt(0)"
                : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]));
-}
-
-SD_DEV bf16x8 cat8(bf16x4 a, bf16x4 b) {
-  bf16x8 r;
-  r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = a[3];
-  r[4] = b[0]; r[5] = b[1]; r[6] = b[2]; r[7] = b[3];
-  return r;
 }
 
 SD_DEV f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }

@@ -8,15 +8,21 @@
 //   NN  (ta=0,tb=1)  dX[M,K] = dY[M,N]  . W[N,K]        (B stored [k][n])
 //   TN  (ta=1,tb=1)  dW[N,K] = dY[M,N]^T . X[M,K]       (A stored [k][m], B stored [k][n])
 //
-// Tile BM x 128 x 64 with BM = 128 or 64 (picked so that the grid fills 256 CUs), 256 threads =
-// 4 waves (2x2), each wave (BM/2) x 64 of v_mfma_f32_16x16x32_bf16.  Operand tiles go HBM -> LDS by
-// 16-byte LDS-DMA (global_load_lds_dwordx4), double buffered; the LDS image is lane-linear, so the
-// bank-conflict swizzle is applied to the per-lane SOURCE address and undone on the fragment read.
-// K-contiguous operands are read with ds_read_b128, operands whose contraction index is the slow
-// one with ds_read_b64_tr_b16 (hardware transpose).  The accumulator is produced transposed
-// (mfma(Bfrag, Afrag)) so a lane owns 4 consecutive n; it is staged through LDS as fp32 and written
-// out in full 16-byte row pieces with the epilogue fused.  Optional split-K (very long K, few
-// tiles): each K slice writes an fp32 slab, a second kernel sums the slabs in a fixed order.
+// Two kernels.  gemm_bf16_kernel: tile BM x 128 x 64 (BM = 256 / 128 / 64, picked per shape so that the grid covers
+// the 256 CUs), 4 or 8 waves as (BM/64 or 2) x 2, each wave a (BM / rows-of-waves) x 64 block of
+// v_mfma_f32_16x16x32_bf16; NST-deep LDS ring, the wait for tile t is a COUNTED s_waitcnt vmcnt that leaves the
+// younger tiles in flight across a raw s_barrier.  gemm_stag_kernel: 256 x 128 x 64, 8 waves, the two 4-wave halves
+// run half a K-step apart (one loads while the other computes) -- the dominant kernel of the step.
+// Common to both: operand tiles go HBM -> LDS by 16-byte LDS-DMA through buffer descriptors
+// (buffer_load_dwordx4 ... lds: loop-invariant per-lane offsets, scalar K advance, hardware range check = zero
+// fill; a pointer-based path with a zero page remains for K % 64 != 0 with two K-contiguous operands); the LDS image
+// is lane-linear, so the bank-conflict swizzle is applied to the per-lane SOURCE address and undone on the fragment
+// read.  K-contiguous operands are read with ds_read_b128, operands whose contraction index is the slow one with
+// ds_read_b64_tr_b16 (hardware transpose, issued as asm so hipcc does not drain the DMA in front of it).  The
+// accumulator is produced transposed (mfma(Bfrag, Afrag)) so a lane owns 4 consecutive n; it is staged through LDS
+// as fp32 and written out in full 16-byte row pieces with the epilogue fused (+ residual / accumulate).  Split-K
+// (contraction over the vocabulary): every K slice writes an fp32 slab; a reduce kernel -- or the consumer itself
+// (sd_rmsnorm_bwd_slabs) -- sums the slabs in a fixed order.
 #include "sd_common.cuh"
 #include "../../include/sd_hip.h"
 #include "sd_prof.h"
@@ -102,21 +108,13 @@ struct FastStage {
 };
 
 // Fragment of 16 rows x 32 k for v_mfma_f32_16x16x32_bf16: lane l holds row (l&15), k = 8(l>>4)+j.
+// K-contiguous operand image: one ds_read_b128 (transposed operands: load_frags_tr below).
 template <bool TX, int ROWS>
 SD_DEV bf16x8 load_frag(const char* lds_tile, int row16_base, int kk, int lane) {
-  if constexpr (!TX) {
-    const int r = row16_base + (lane & 15);
-    const int c = kk * 4 + (lane >> 4);
-    return *(const bf16x8*)(lds_tile + ((r * 8 + (c ^ (r & 7))) << 4));
-  } else {
-    const int g = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3;
-    const int ch = row16_base >> 4;
-    const int k0 = kk * 32 + 8 * g + q;
-    const int k1 = k0 + 4;
-    bf16x4 lo = lds_tr16(lds_tile + k0 * (ROWS * 2) + ((ch ^ swz_t<ROWS>(k0)) << 5) + 8 * pp);
-    bf16x4 hi = lds_tr16(lds_tile + k1 * (ROWS * 2) + ((ch ^ swz_t<ROWS>(k1)) << 5) + 8 * pp);
-    return cat8(lo, hi);
-  }
+  static_assert(!TX, "transposed operands are read by load_frags_tr");
+  const int r = row16_base + (lane & 15);
+  const int c = kk * 4 + (lane >> 4);
+  return *(const bf16x8*)(lds_tile + ((r * 8 + (c ^ (r & 7))) << 4));
 }
 
 // Transposed-operand fragments for one kk step, NF fragments (16 rows each from row_base): issues the 2*NF
@@ -505,7 +503,6 @@ int g_force_variant = 0;
 
 int dispatch(const void* A, const void* B, void* C, const void* R, float* slabs, int splits, int M, int N, int K,
              long lda, long ldb, long ldc, long ldr, int ta, int tb, hipStream_t st) {
-  // 128-row tiles unless they leave the 256 CUs under-filled; deeper ring for the small tile
   // Picked from tests/bench_shapes.py --tune --cold on MI355X (weight operand HBM-cold, as in the real step
   // where every layer streams its own weights).  NT/NN read weights: latency-bound on HBM misses, so large
   // tiles / deeper rings win whenever the grid still covers the 256 CUs; TN (dW) reads two warm activations.

@@ -80,7 +80,6 @@ __global__ __launch_bounds__(NT) void kd_fwd_kernel(const T* __restrict__ S, con
                                                     RowStats* __restrict__ stats, int rows, int Tlen, int V, int K,
                                                     float temperature) {
   __shared__ float sc[32];
-  __shared__ float k_q[KMAX];
   const int row = blockIdx.x;
   long y = 0;
   const bool valid = row_valid(labels, mask, row, Tlen, &y);
@@ -167,7 +166,6 @@ __global__ __launch_bounds__(NT) void kd_fwd_kernel(const T* __restrict__ S, con
     distill = block_sum<NT>(term, sc);
     teacher = block_sum<NT>(hv, sc);   // sum of teacher log-probs at the label, over hits
     hits = block_sum<NT>(hc, sc);
-    (void)k_q;
   }
   if (threadIdx.x == 0) stats[row] = RowStats{lse1, lseT, t_lseT, 1.f, task, distill, teacher, hits};
 }

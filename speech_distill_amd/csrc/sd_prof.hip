@@ -12,7 +12,7 @@ size_t g_pool_next = 0;
 hipEvent_t get_event() {
   if (g_pool_next < g_pool.size()) return g_pool[g_pool_next++];
   hipEvent_t e;
-  hipEventCreate(&e);
+  (void)hipEventCreate(&e);
   g_pool.push_back(e);
   ++g_pool_next;
   return e;
@@ -21,11 +21,11 @@ hipEvent_t get_event() {
 
 void sd_prof_open(int kind, double work, hipStream_t st, int* slot) {
   Rec r{kind, work, get_event(), get_event()};
-  hipEventRecord(r.a, st);
+  (void)hipEventRecord(r.a, st);
   g_recs.push_back(r);
   *slot = (int)g_recs.size() - 1;
 }
-void sd_prof_close(int slot, hipStream_t st) { hipEventRecord(g_recs[slot].b, st); }
+void sd_prof_close(int slot, hipStream_t st) { (void)hipEventRecord(g_recs[slot].b, st); }
 
 extern "C" int sd_prof_begin(void) {
   g_recs.clear();
