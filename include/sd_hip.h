@@ -54,6 +54,14 @@ int sd_gemm_bf16_splitk_partial(const void* A, const void* B, void* C, int M, in
                                 int64_t ldc, int trans_a, int trans_b, void* workspace, int64_t workspace_bytes,
                                 int* nsplit_out, void* stream);
 
+/* Fused forward GEMMs (fall back to the separate launchers when they return SD_ERR_UNSUPPORTED):
+ * sd_gemm_swiglu: act [M,I] = silu(x Wg^T) * (x Wu^T), wgu = [gate rows | up rows] [2I,K]; gu_out [M,2I] nullable (HF:81-83).
+ * sd_gemm_qkv_rope: raw q|k|v [M,(Hq+2Hkv)*128] plus RMS-normalised + RoPE-rotated q|k [M,(Hq+Hkv)*128] (HF:252-257). */
+int sd_gemm_swiglu(const void* x, const void* wgu, void* gu_out, void* act_out, int M, int I, int K, void* stream);
+int sd_gemm_qkv_rope(const void* x, const void* wqkv, void* qkv_out, void* qk_out, const void* q_gain, const void* k_gain,
+                     const void* cos_tab, const void* sin_tab, int M, int T, int Hq, int Hkv, int K, float eps,
+                     void* stream);
+
 /* ---- RMSNorm (HF:59-64).  rstd (fp32 [M], nullable in fwd) is saved for backward. */
 int sd_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int M, int H, float eps, void* stream);
 int64_t sd_rmsnorm_bwd_workspace_bytes(int M, int H);

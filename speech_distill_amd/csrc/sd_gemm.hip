@@ -78,7 +78,8 @@ struct FastStage {
   __amdgpu_buffer_rsrc_t rsrc;
 #endif
   long kstep;  // bytes per k element step of BK
-  SD_DEV void init(const bf16* g, long ld, int row0, unsigned num_bytes, int w, int lane) {
+  // hi_delta: rows 64.. of the tile come from row0 + r + hi_delta (EPI 3: the up-projection rows)
+  SD_DEV void init(const bf16* g, long ld, int row0, unsigned num_bytes, int w, int lane, int hi_delta = 0) {
 #if defined(__HIP_DEVICE_COMPILE__)
     rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)g, 0, (int)num_bytes, 0x00020000);
 #endif
@@ -87,7 +88,7 @@ struct FastStage {
       const int p = (w * NI + i) * 64 + lane;
       if constexpr (!TX) {
         const int r = p >> 3, s = p & 7, c = s ^ (r & 7);
-        voff[i] = (int)((((long)(row0 + r)) * ld + c * 8) * 2);
+        voff[i] = (int)((((long)(row0 + r + (r >= 64 ? hi_delta : 0))) * ld + c * 8) * 2);
       } else {
         constexpr int UPR = ROWS / 8;
         const int k = p / UPR, u = p % UPR;
@@ -138,6 +139,133 @@ SD_DEV void load_frags_tr(const char* lds_tile, int row_base, int kk, int lane, 
   for (int f = 0; f < NF; ++f) out[f] = cat8_u64(raw[2 * f], raw[2 * f + 1]);
 }
 
+// Extra operands of the fused epilogues.
+//   EPI 3 (gate|up GEMM + SwiGLU, HF:81-83): the B tile of column-tile tn is gate rows [64tn,64tn+64) followed by up
+//          rows [I+64tn, ...), so a 128-column C tile holds gate and up of the SAME 64 outputs; act = silu(gate)*up
+//          is written to out2 [M,I], gate|up (needed by the backward) to C [M,2I] when C != nullptr.
+//   EPI 4 (q|k|v GEMM + per-head RMSNorm + rotate-half RoPE, HF:252-257,121-170): one 128-column tile is exactly one
+//          head; raw q|k|v go to C, normalised + rotated q|k heads to out2 [M,(Hq+Hkv)*128].
+struct EpiArgs {
+  bf16* out2;
+  long ld2;
+  const bf16 *g0, *g1, *cos_t, *sin_t;
+  int T, Hq, Hkv, I;
+  float eps;
+};
+
+// fp32 C tile in LDS ([BM][128], 16-byte chunks XOR-swizzled by row) -> global, 8 columns per thread.
+// Global operands of the epilogue (residual rows for EPI 1; cos / sin rows for EPI 4) are loaded into registers
+// BEFORE the K loop (epi_preload): with one or two workgroups per CU nothing else would hide their latency
+// between the last MFMA and the stores (measured: 7-9 us per launch when loaded inside the epilogue).
+template <int EPI, int BM, int NTHR>
+struct EpiPre {
+  static constexpr int IT = BM * 16 / NTHR;
+  bf16x8 a[(EPI == 1 || EPI == 4) ? IT : 1];
+  bf16x8 b[EPI == 4 ? IT : 1];
+  bf16x8 gain;
+};
+
+template <int EPI, int BM, int NTHR>
+SD_DEV void epi_preload(EpiPre<EPI, BM, NTHR>& pre, const bf16* R, const EpiArgs& ea, int M, int N, long ldr, int m0,
+                        int n0, int tn) {
+  if constexpr (EPI == 1 || EPI == 4) {
+#pragma unroll
+    for (int it = 0; it < BM * 16 / NTHR; ++it) {
+      const int q = it * NTHR + threadIdx.x;
+      const int m = q >> 4, oc = q & 15;
+      const int gm = m0 + m, gn = n0 + oc * 8;
+      if constexpr (EPI == 1) {
+        const bool ok = gm < M && gn < N;
+        bf16x8 z = {};
+        pre.a[it] = ok ? *(const bf16x8*)(R + (long)gm * ldr + gn) : z;
+      } else {
+        const int gmc = gm < M ? gm : M - 1;
+        const int t = gmc % ea.T;
+        pre.a[it] = *(const bf16x8*)(ea.cos_t + (long)t * 128 + oc * 8);
+        pre.b[it] = *(const bf16x8*)(ea.sin_t + (long)t * 128 + oc * 8);
+      }
+    }
+    if constexpr (EPI == 4) pre.gain = *(const bf16x8*)((tn < ea.Hq ? ea.g0 : ea.g1) + (threadIdx.x & 15) * 8);
+  }
+}
+
+template <int EPI, int BM, int NTHR>
+SD_DEV void write_out(const float* cs, bf16* C, const EpiPre<EPI, BM, NTHR>& pre, float* slabs, const EpiArgs& ea, int M,
+                      int N, long ldc, int m0, int n0, int tn) {
+#pragma unroll
+  for (int it = 0; it < BM * 16 / NTHR; ++it) {
+    const int q = it * NTHR + threadIdx.x;
+    const int m = q >> 4, oc = q & 15;
+    const int gm = m0 + m, gn = n0 + oc * 8;
+    const bool ok = gm < M && gn < N;
+    const f32x4 lo = *(const f32x4*)(cs + m * 128 + (((2 * oc) ^ (m & 15)) << 2));
+    const f32x4 hi = *(const f32x4*)(cs + m * 128 + (((2 * oc + 1) ^ (m & 15)) << 2));
+    float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    if constexpr (EPI == 2) {
+      if (ok) {
+        float* dst = slabs + ((long)blockIdx.y * M + gm) * N + gn;
+        *(f32x4*)dst = lo;
+        *(f32x4*)(dst + 4) = hi;
+      }
+    } else if constexpr (EPI == 3) {
+      // columns 0..63 = gate, 64..127 = up of outputs 64*tn + (0..63); threads oc < 8 own one 8-wide output chunk
+      const int oc2 = (oc & 7) + 8;
+      const f32x4 ulo = *(const f32x4*)(cs + m * 128 + (((2 * oc2) ^ (m & 15)) << 2));
+      const f32x4 uhi = *(const f32x4*)(cs + m * 128 + (((2 * oc2 + 1) ^ (m & 15)) << 2));
+      const float u[8] = {ulo[0], ulo[1], ulo[2], ulo[3], uhi[0], uhi[1], uhi[2], uhi[3]};
+      const int col = tn * 64 + oc * 8;
+      if (oc < 8 && gm < M && col < ea.I) {
+        bf16x8 gb, ub, ab;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          gb[e] = (bf16)v[e];
+          ub[e] = (bf16)u[e];
+          const float gf = (float)gb[e], uf = (float)ub[e];
+          ab[e] = (bf16)(gf / (1.f + __expf(-gf)) * uf);
+        }
+        if (C) {
+          *(bf16x8*)(C + (long)gm * ldc + col) = gb;
+          *(bf16x8*)(C + (long)gm * ldc + ea.I + col) = ub;
+        }
+        *(bf16x8*)(ea.out2 + (long)gm * ea.ld2 + col) = ab;
+      }
+    } else if constexpr (EPI == 4) {
+      bf16x8 raw;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) raw[e] = (bf16)v[e];
+      if (ok) *(bf16x8*)(C + (long)gm * ldc + gn) = raw;
+      if (tn < ea.Hq + ea.Hkv) {  // block-uniform: q or k head -> RMSNorm over the 128 columns, then RoPE
+        float f[8], ss = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { f[e] = (float)raw[e]; ss += f[e] * f[e]; }
+        ss += __shfl_xor(ss, 1, 64); ss += __shfl_xor(ss, 2, 64); ss += __shfl_xor(ss, 4, 64); ss += __shfl_xor(ss, 8, 64);
+        const float rs = rsqrtf(ss * (1.f / 128.f) + ea.eps);
+        const bf16x8 gv = pre.gain, cv = pre.a[it], sv = pre.b[it];
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float nrm = (float)(bf16)((float)gv[e] * (float)(bf16)(f[e] * rs));
+          const float pr = __shfl_xor(nrm, 8, 64);
+          const float rot = (oc < 8) ? -pr : pr;
+          o[e] = (bf16)(nrm * (float)cv[e] + rot * (float)sv[e]);
+        }
+        if (ok) *(bf16x8*)(ea.out2 + (long)gm * ea.ld2 + gn) = o;
+      }
+    } else {
+      if (ok) {
+        if constexpr (EPI == 1) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += (float)pre.a[it][e];
+        }
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
+        *(bf16x8*)(C + (long)gm * ldc + gn) = o;
+      }
+    }
+  }
+}
+
 // EPI: 0 = bf16 out, 1 = bf16 out + residual, 2 = fp32 slab out (split-K)
 // NST-deep LDS ring: tile t+NST-1 is issued while tile t is computed; the wait for tile t is a COUNTED
 // s_waitcnt vmcnt that leaves the NST-2 younger tiles in flight across the (raw) barrier.  Tiles past
@@ -146,7 +274,7 @@ template <int BM, int NST, bool TA, bool TB, int EPI, bool FAST>
 __global__ __launch_bounds__(BM == 256 ? 512 : 256, (BM == 256 ? 2 : (NST * (BM + 128) * 128 <= 80 * 1024 ? 2 : 1))) void gemm_bf16_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B, bf16* C,
                                                         const bf16* R, float* __restrict__ slabs, int M, int N, int K,
                                                         long lda, long ldb, long ldc, long ldr, int tiles_m, int tiles_n,
-                                                        int k_tiles_per_split) {
+                                                        int k_tiles_per_split, EpiArgs ea) {
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
   constexpr int NW = (BM == 256) ? 8 : 4;          // waves: (NW/2) along M x 2 along N
   constexpr int NTHR = NW * 64;
@@ -163,6 +291,9 @@ __global__ __launch_bounds__(BM == 256 ? 512 : 256, (BM == 256 ? 2 : (NST * (BM 
   const int tm = tile % tiles_m, tn = tile / tiles_m;
   const int m0 = tm * BM, n0 = tn * BN;
 
+  EpiPre<EPI, BM, NTHR> pre;
+  epi_preload<EPI, BM, NTHR>(pre, R, ea, M, N, ldr, m0, n0, tn);
+
   f32x4 acc[MT][4];
 #pragma unroll
   for (int i = 0; i < MT; ++i)
@@ -178,7 +309,8 @@ __global__ __launch_bounds__(BM == 256 ? 512 : 256, (BM == 256 ? 2 : (NST * (BM 
   FastStage<TB, BN, NW> fb;
   if constexpr (FAST) {
     fa.init(A, lda, m0, (unsigned)((TA ? ((long)(K - 1) * lda + M) : ((long)(M - 1) * lda + K)) * 2), w, lane);
-    fb.init(B, ldb, n0, (unsigned)((TB ? ((long)(K - 1) * ldb + N) : ((long)(N - 1) * ldb + K)) * 2), w, lane);
+    fb.init(B, ldb, EPI == 3 ? tn * 64 : n0, (unsigned)((TB ? ((long)(K - 1) * ldb + N) : ((long)(N - 1) * ldb + K)) * 2),
+            w, lane, EPI == 3 ? ea.I - 64 : 0);
   }
 #pragma unroll
   for (int s = 0; s < NST - 1; ++s) {
@@ -244,32 +376,7 @@ __global__ __launch_bounds__(BM == 256 ? 512 : 256, (BM == 256 ? 2 : (NST * (BM 
     }
   }
   __syncthreads();
-#pragma unroll
-  for (int it = 0; it < BM * 16 / NTHR; ++it) {
-    const int q = it * NTHR + threadIdx.x;
-    const int m = q >> 4, oc = q & 15;
-    const int gm = m0 + m, gn = n0 + oc * 8;
-    if (gm < M && gn < N) {
-      f32x4 lo = *(const f32x4*)(cs + m * 128 + (((2 * oc) ^ (m & 15)) << 2));
-      f32x4 hi = *(const f32x4*)(cs + m * 128 + (((2 * oc + 1) ^ (m & 15)) << 2));
-      if constexpr (EPI == 2) {
-        float* dst = slabs + ((long)blockIdx.y * M + gm) * N + gn;
-        *(f32x4*)dst = lo;
-        *(f32x4*)(dst + 4) = hi;
-      } else {
-        float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        if constexpr (EPI == 1) {
-          bf16x8 r = *(const bf16x8*)(R + (long)gm * ldr + gn);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += (float)r[e];
-        }
-        bf16x8 o;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
-        *(bf16x8*)(C + (long)gm * ldc + gn) = o;
-      }
-    }
-  }
+  write_out<EPI, BM, NTHR>(cs, C, pre, slabs, ea, M, N, ldc, m0, n0, tn);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -290,7 +397,7 @@ template <bool TA, bool TB, int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_stag_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B, bf16* C,
                                                            const bf16* R, float* __restrict__ slabs, int M, int N, int K,
                                                            long lda, long ldb, long ldc, long ldr, int tiles_m,
-                                                           int tiles_n, int k_tiles_per_split) {
+                                                           int tiles_n, int k_tiles_per_split, EpiArgs ea) {
   constexpr int BM = 256, NW = 8, NST = 3;
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;  // 48 KiB
   constexpr int LOADS = (BM + BN) / (8 * NW);                                             // 6 per wave per tile
@@ -302,6 +409,9 @@ __global__ __launch_bounds__(512, 2) void gemm_stag_kernel(const bf16* __restric
   const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
   const int tm = tile % tiles_m, tn = tile / tiles_m;
   const int m0 = tm * BM, n0 = tn * BN;
+
+  EpiPre<EPI, 256, 512> pre;
+  epi_preload<EPI, 256, 512>(pre, R, ea, M, N, ldr, m0, n0, tn);
 
   f32x4 acc[4][4];
 #pragma unroll
@@ -316,7 +426,8 @@ __global__ __launch_bounds__(512, 2) void gemm_stag_kernel(const bf16* __restric
   FastStage<TA, BM, NW> fa;
   FastStage<TB, BN, NW> fb;
   fa.init(A, lda, m0, (unsigned)((TA ? ((long)(K - 1) * lda + M) : ((long)(M - 1) * lda + K)) * 2), w, lane);
-  fb.init(B, ldb, n0, (unsigned)((TB ? ((long)(K - 1) * ldb + N) : ((long)(N - 1) * ldb + K)) * 2), w, lane);
+  fb.init(B, ldb, EPI == 3 ? tn * 64 : n0, (unsigned)((TB ? ((long)(K - 1) * ldb + N) : ((long)(N - 1) * ldb + K)) * 2), w,
+          lane, EPI == 3 ? ea.I - 64 : 0);
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
     fa.issue((kt0 + s) * BK, smem + s * STAGE, w);
@@ -387,32 +498,7 @@ __global__ __launch_bounds__(512, 2) void gemm_stag_kernel(const bf16* __restric
     }
   }
   __syncthreads();
-#pragma unroll
-  for (int it = 0; it < 8; ++it) {
-    const int q = it * 512 + threadIdx.x;
-    const int m = q >> 4, oc = q & 15;
-    const int gm = m0 + m, gn = n0 + oc * 8;
-    if (gm < M && gn < N) {
-      f32x4 lo = *(const f32x4*)(cs + m * 128 + (((2 * oc) ^ (m & 15)) << 2));
-      f32x4 hi = *(const f32x4*)(cs + m * 128 + (((2 * oc + 1) ^ (m & 15)) << 2));
-      if constexpr (EPI == 2) {
-        float* dst = slabs + ((long)blockIdx.y * M + gm) * N + gn;
-        *(f32x4*)dst = lo;
-        *(f32x4*)(dst + 4) = hi;
-      } else {
-        float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        if constexpr (EPI == 1) {
-          bf16x8 r = *(const bf16x8*)(R + (long)gm * ldr + gn);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += (float)r[e];
-        }
-        bf16x8 o;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
-        *(bf16x8*)(C + (long)gm * ldc + gn) = o;
-      }
-    }
-  }
+  write_out<EPI, 256, 512>(cs, C, pre, slabs, ea, M, N, ldc, m0, n0, tn);
 }
 
 // C = sum_s slab[s] (+ R), fixed order
@@ -446,7 +532,7 @@ thread_local bool g_skip_reduce = false;  // set by sd_gemm_bf16_splitk_partial 
 
 template <int BM, int NST, bool TA, bool TB>
 int launch(const void* A, const void* B, void* C, const void* R, float* slabs, int splits, int M, int N, int K, long lda,
-           long ldb, long ldc, long ldr, hipStream_t st) {
+           long ldb, long ldc, long ldr, int epi_kind, const EpiArgs& ea, hipStream_t st) {
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   const int kt_all = (K + BK - 1) / BK;
   const int per = (kt_all + splits - 1) / splits;
@@ -462,16 +548,20 @@ int launch(const void* A, const void* B, void* C, const void* R, float* slabs, i
   do {                                                                                                               \
     if constexpr (BM == 256 && NST == 9) {                                                                           \
       hipLaunchKernelGGL((gemm_stag_kernel<TA, TB, EPI>), grid, block, 0, st, (const bf16*)A, (const bf16*)B,          \
-                         (bf16*)C, (const bf16*)R, slabs, M, N, K, lda, ldb, ldc, ldr, tiles_m, tiles_n, per);         \
-    } else if (fast)                                                                                                 \
-      hipLaunchKernelGGL((gemm_bf16_kernel<BM, (NST == 9 ? 3 : NST), TA, TB, EPI, true>), grid, block, 0, st, (const bf16*)A,          \
-                         (const bf16*)B, (bf16*)C, (const bf16*)R, slabs, M, N, K, lda, ldb, ldc, ldr, tiles_m,       \
-                         tiles_n, per);                                                                              \
+                         (bf16*)C, (const bf16*)R, slabs, M, N, K, lda, ldb, ldc, ldr, tiles_m, tiles_n, per, ea);     \
+    } else if (fast || EPI >= 3)                                                                                     \
+      hipLaunchKernelGGL((gemm_bf16_kernel<BM, (NST == 9 ? 3 : NST), TA, TB, EPI, true>), grid, block, 0, st,          \
+                         (const bf16*)A, (const bf16*)B, (bf16*)C, (const bf16*)R, slabs, M, N, K, lda, ldb, ldc, ldr, \
+                         tiles_m, tiles_n, per, ea);                                                                 \
     else                                                                                                             \
-      hipLaunchKernelGGL((gemm_bf16_kernel<BM, (NST == 9 ? 3 : NST), TA, TB, EPI, false>), grid, block, 0, st, (const bf16*)A,         \
-                         (const bf16*)B, (bf16*)C, (const bf16*)R, slabs, M, N, K, lda, ldb, ldc, ldr, tiles_m,       \
-                         tiles_n, per);                                                                              \
+      hipLaunchKernelGGL((gemm_bf16_kernel<BM, (NST == 9 ? 3 : NST), TA, TB, (EPI >= 3 ? 0 : EPI), false>), grid,      \
+                         block, 0, st, (const bf16*)A, (const bf16*)B, (bf16*)C, (const bf16*)R, slabs, M, N, K, lda,  \
+                         ldb, ldc, ldr, tiles_m, tiles_n, per, ea);                                                  \
   } while (0)
+  if constexpr (!TA && !TB) {
+    if (epi_kind == 3) { if (!fast) return SD_ERR_UNSUPPORTED; SD_GEMM_GO(3); SD_CHECK_LAUNCH(); return 0; }
+    if (epi_kind == 4) { if (!fast) return SD_ERR_UNSUPPORTED; SD_GEMM_GO(4); SD_CHECK_LAUNCH(); return 0; }
+  }
   if (splits > 1) SD_GEMM_GO(2);
   else if (R) SD_GEMM_GO(1);
   else SD_GEMM_GO(0);
@@ -502,7 +592,9 @@ int check_args(const void* A, const void* B, const void* C, const void* R, int M
 int g_force_variant = 0;
 
 int dispatch(const void* A, const void* B, void* C, const void* R, float* slabs, int splits, int M, int N, int K,
-             long lda, long ldb, long ldc, long ldr, int ta, int tb, hipStream_t st) {
+             long lda, long ldb, long ldc, long ldr, int ta, int tb, hipStream_t st, int epi_kind = 0,
+             const EpiArgs* eap = nullptr) {
+  const EpiArgs ea = eap ? *eap : EpiArgs{};
   // Picked from tests/bench_shapes.py --tune --cold on MI355X (weight operand HBM-cold, as in the real step
   // where every layer streams its own weights).  NT/NN read weights: latency-bound on HBM misses, so large
   // tiles / deeper rings win whenever the grid still covers the 256 CUs; TN (dW) reads two warm activations.
@@ -532,7 +624,7 @@ int dispatch(const void* A, const void* B, void* C, const void* R, float* slabs,
   SdProfScope prof(ta ? SD_K_GEMM_TN : (tb ? SD_K_GEMM_NN : ((bm == 256 && nst == 9) ? SD_K_GEMM_NT_STAG : SD_K_GEMM_NT)),
                    2.0 * M * N * K, st);
 #define SD_GO(BM_, NST_, TA_, TB_) \
-  return launch<BM_, NST_, TA_, TB_>(A, B, C, R, slabs, splits, M, N, K, lda, ldb, ldc, ldr, st)
+  return launch<BM_, NST_, TA_, TB_>(A, B, C, R, slabs, splits, M, N, K, lda, ldb, ldc, ldr, epi_kind, ea, st)
 #define SD_PICK(TA_, TB_)                                   \
   do {                                                      \
     if (bm == 256 && nst == 9 && stag_ok) SD_GO(256, 9, TA_, TB_); \
@@ -608,4 +700,39 @@ extern "C" int sd_gemm_bf16_splitk_partial(const void* A, const void* B, void* C
                           (hipStream_t)stream);
   g_skip_reduce = false;
   return rc;
+}
+
+// gate|up projection with SwiGLU fused into the epilogue (HF:81-83): act [M,I] = silu(x Wg^T) * (x Wu^T);
+// wgu = [gate rows | up rows] ([2I,K], torch layout); gu_out [M,2I] (gate | up, for the backward) may be NULL.
+extern "C" int sd_gemm_swiglu(const void* x, const void* wgu, void* gu_out, void* act_out, int M, int I, int K,
+                              void* stream) {
+  if (M <= 0 || I <= 0 || K <= 0 || (I % 64) || (K % BK)) return SD_ERR_UNSUPPORTED;
+  if (((uintptr_t)x | (uintptr_t)wgu | (uintptr_t)gu_out | (uintptr_t)act_out) & 15) return SD_ERR_ALIGN;
+  EpiArgs ea{};
+  ea.out2 = (bf16*)act_out;
+  ea.ld2 = I;
+  ea.I = I;
+  return dispatch(x, wgu, gu_out, nullptr, nullptr, 1, M, 2 * I, K, K, K, 2 * I, 0, 0, 0, (hipStream_t)stream, 3, &ea);
+}
+
+// q|k|v projection with the per-head q/k RMSNorm and rotate-half RoPE fused into the epilogue (HF:252-257, 121-170):
+// qkv_out [M,(Hq+2Hkv)*128] raw projections (V for attention, q/k for the backward), qk_out [M,(Hq+Hkv)*128] rotated.
+extern "C" int sd_gemm_qkv_rope(const void* x, const void* wqkv, void* qkv_out, void* qk_out, const void* q_gain,
+                                const void* k_gain, const void* cos_tab, const void* sin_tab, int M, int T, int Hq,
+                                int Hkv, int K, float eps, void* stream) {
+  if (M <= 0 || T <= 0 || (M % T) || K <= 0 || (K % BK) || !qkv_out || !qk_out) return SD_ERR_UNSUPPORTED;
+  if (((uintptr_t)x | (uintptr_t)wqkv | (uintptr_t)qkv_out | (uintptr_t)qk_out) & 15) return SD_ERR_ALIGN;
+  EpiArgs ea{};
+  ea.out2 = (bf16*)qk_out;
+  ea.ld2 = (long)(Hq + Hkv) * 128;
+  ea.g0 = (const bf16*)q_gain;
+  ea.g1 = (const bf16*)k_gain;
+  ea.cos_t = (const bf16*)cos_tab;
+  ea.sin_t = (const bf16*)sin_tab;
+  ea.T = T;
+  ea.Hq = Hq;
+  ea.Hkv = Hkv;
+  ea.eps = eps;
+  const int N = (Hq + 2 * Hkv) * 128;
+  return dispatch(x, wqkv, qkv_out, nullptr, nullptr, 1, M, N, K, K, K, N, 0, 0, 0, (hipStream_t)stream, 4, &ea);
 }

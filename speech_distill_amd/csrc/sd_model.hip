@@ -129,14 +129,29 @@ extern "C" int sd_qwen3_forward(const sd_qwen3_dims* d, const sd_qwen3_params* p
     if (save) x_out = (l + 1 < s.L) ? base + (int64_t)(l + 1) * s.per_layer() : x_last;
     else x_out = (l + 1 < s.L) ? ((x_cur == pong) ? base : pong) : x_last;
     RUN(sd_rmsnorm_fwd(a.x_in, w.ln1, a.xn1, (float*)a.rstd1, s.M, s.h, d->eps, stream));
-    RUN(sd_gemm_bf16(a.xn1, w.wqkv, a.qkv, nullptr, s.M, s.QKV, s.h, s.h, s.h, s.QKV, 0, 0, 0, stream));
-    RUN(sd_qknorm_rope_fwd(a.qkv, w.q_gain, w.k_gain, cos_tab, sin_tab, a.qk, s.M, T, s.Hq, s.Hkv, d->eps, stream));
+    // q|k|v projection with q/k-norm + RoPE in the GEMM epilogue (one head = one 128-column tile)
+    int rc = sd_gemm_qkv_rope(a.xn1, w.wqkv, a.qkv, a.qk, w.q_gain, w.k_gain, cos_tab, sin_tab, s.M, T, s.Hq, s.Hkv, s.h,
+                              d->eps, stream);
+    if (rc == SD_ERR_UNSUPPORTED) {
+      RUN(sd_gemm_bf16(a.xn1, w.wqkv, a.qkv, nullptr, s.M, s.QKV, s.h, s.h, s.h, s.QKV, 0, 0, 0, stream));
+      RUN(sd_qknorm_rope_fwd(a.qkv, w.q_gain, w.k_gain, cos_tab, sin_tab, a.qk, s.M, T, s.Hq, s.Hkv, d->eps, stream));
+    } else if (rc) {
+      return rc;
+    }
     RUN(sd_attn_fwd(a.qk, a.qk + (int64_t)s.QD * 2, a.qkv + (int64_t)(s.QD + s.KD) * 2, a.ao, (float*)a.lse, kv_len,
                     s.QK, s.QK, s.QKV, s.QD, B, T, s.Hq, s.Hkv, 128, scale, stream));
     RUN(sd_gemm_bf16(a.ao, w.wo, a.x_mid, a.x_in, s.M, s.h, s.QD, s.QD, s.QD, s.h, s.h, 0, 0, stream));
     RUN(sd_rmsnorm_fwd(a.x_mid, w.ln2, a.xn2, (float*)a.rstd2, s.M, s.h, d->eps, stream));
-    RUN(sd_gemm_bf16(a.xn2, w.wgu, a.gu, nullptr, s.M, 2 * s.I, s.h, s.h, s.h, 2 * s.I, 0, 0, 0, stream));
-    RUN(sd_swiglu_fwd(a.gu, a.act, s.M, s.I, stream));
+    // gate|up projection: SwiGLU runs in the GEMM epilogue when gate|up need not be kept (no backward follows:
+    // the frozen teacher).  With the 2*I-wide store as well the fused epilogue is no faster than the separate
+    // elementwise pass (tests/bench_fused.py), so the student keeps the two-kernel form.
+    rc = save ? SD_ERR_UNSUPPORTED : sd_gemm_swiglu(a.xn2, w.wgu, nullptr, a.act, s.M, s.I, s.h, stream);
+    if (rc == SD_ERR_UNSUPPORTED) {
+      RUN(sd_gemm_bf16(a.xn2, w.wgu, a.gu, nullptr, s.M, 2 * s.I, s.h, s.h, s.h, 2 * s.I, 0, 0, 0, stream));
+      RUN(sd_swiglu_fwd(a.gu, a.act, s.M, s.I, stream));
+    } else if (rc) {
+      return rc;
+    }
     RUN(sd_gemm_bf16(a.act, w.wdown, x_out, a.x_mid, s.M, s.h, s.I, s.I, s.I, s.h, s.h, 0, 0, stream));
     x_cur = x_out;
   }

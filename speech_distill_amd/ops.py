@@ -287,3 +287,25 @@ def rmsnorm_bwd_from_splitk(a, b_kn, x, w, rstd, dres=None):
         check(lib.sd_rmsnorm_bwd2(dy.data_ptr(), x.data_ptr(), w.data_ptr(), rstd.data_ptr(), _p(dres), dx.data_ptr(),
                                   dw.data_ptr(), 0, wsn.data_ptr(), M, N, 0, 0, _stream()), "sd_rmsnorm_bwd2")
     return dx, dw, nsp.value
+
+
+# --------------------------------------------------------------------------------- fused forward GEMMs
+def gemm_swiglu(x, wgu, save_gu=True):
+    """act = silu(x Wg^T) * (x Wu^T) with wgu = [gate rows | up rows]; returns (act, gu or None)."""
+    M, K = x.shape
+    I = wgu.shape[0] // 2
+    act = torch.empty(M, I, dtype=torch.bfloat16, device=x.device)
+    gu = torch.empty(M, 2 * I, dtype=torch.bfloat16, device=x.device) if save_gu else None
+    check(load_lib().sd_gemm_swiglu(x.data_ptr(), wgu.data_ptr(), _p(gu), act.data_ptr(), M, I, K, _stream()), "sd_gemm_swiglu")
+    return act, gu
+
+
+def gemm_qkv_rope(x, wqkv, q_gain, k_gain, cos, sin, T, Hq, Hkv, eps=1e-6):
+    """raw q|k|v and RMS-normalised + RoPE-rotated q|k in one launch."""
+    M, K = x.shape
+    qkv = torch.empty(M, (Hq + 2 * Hkv) * 128, dtype=torch.bfloat16, device=x.device)
+    qk = torch.empty(M, (Hq + Hkv) * 128, dtype=torch.bfloat16, device=x.device)
+    check(load_lib().sd_gemm_qkv_rope(x.data_ptr(), wqkv.data_ptr(), qkv.data_ptr(), qk.data_ptr(), q_gain.data_ptr(),
+                                      k_gain.data_ptr(), cos.data_ptr(), sin.data_ptr(), M, T, Hq, Hkv, K, eps, _stream()),
+          "sd_gemm_qkv_rope")
+    return qkv, qk

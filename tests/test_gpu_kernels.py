@@ -112,6 +112,35 @@ def test_gemm_staggered_kernel_random(ops, ta, tb):
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
 
 
+@pytest.mark.parametrize("bm,nst", [(0, 0), (64, 4), (128, 3), (256, 9)])
+def test_gemm_fused_epilogues_equal_the_separate_kernels(ops, bm, nst):
+    """q|k|v GEMM + q/k-norm + RoPE, and gate|up GEMM + SwiGLU, fused into the GEMM epilogue: bit-identical to the
+    separate launchers (same bf16 roundings), for every kernel variant that can run them; ragged M."""
+    g = torch.Generator().manual_seed(31)
+    B, T, Hq, Hkv, K, I = 2, 75, 4, 2, 256, 192
+    M = B * T
+    x = to_dev(bf(torch.randn(M, K, generator=g)))
+    wqkv = to_dev(bf(torch.randn((Hq + 2 * Hkv) * 128, K, generator=g) * 0.1))
+    wgu = to_dev(bf(torch.randn(2 * I, K, generator=g) * 0.1))
+    qg, kg = to_dev(bf(1 + 0.2 * torch.randn(128, generator=g))), to_dev(bf(1 + 0.2 * torch.randn(128, generator=g)))
+    cos, sin = ops.rope_tables(T, dev())
+    lib = ops.load_lib()
+    qkv_ref = ops.gemm(x, wqkv)
+    qk_ref = ops.qknorm_rope_fwd(qkv_ref, qg, kg, cos, sin, T, Hq, Hkv)
+    gu_ref = ops.gemm(x, wgu)
+    act_ref = ops.swiglu_fwd(gu_ref)
+    lib.sd_gemm_force_variant(bm, nst)
+    try:
+        qkv, qk = ops.gemm_qkv_rope(x, wqkv, qg, kg, cos, sin, T, Hq, Hkv)
+        act, gu = ops.gemm_swiglu(x, wgu)
+        act2, none = ops.gemm_swiglu(x, wgu, save_gu=False)
+    finally:
+        lib.sd_gemm_force_variant(0, 0)
+    assert torch.equal(qkv, qkv_ref) and torch.equal(gu, gu_ref) and none is None
+    assert torch.equal(qk, qk_ref), float((qk.float() - qk_ref.float()).abs().max())
+    assert torch.equal(act, act_ref) and torch.equal(act2, act_ref), float((act.float() - act_ref.float()).abs().max())
+
+
 def test_gemm_split_k(ops):
     """few tiles + long K -> fp32 slabs + fixed-order reduce (the lm_head dX shape class)."""
     g = torch.Generator().manual_seed(6)
