@@ -91,6 +91,9 @@ def main():
     ap.add_argument("--cpu-sample-tokens", type=int, default=512)
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL over xGMI) | gloo (single-GPU rehearsal of the N>1 path)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="run the N>1 code path (process group, bucket all-reduce, embedding-row exchange) even "
+                         "with one rank: a one-GPU rehearsal of the RCCL calls")
     ap.add_argument("--serial-teacher", action="store_true", help="teacher forward on the student's stream (no overlap)")
     ap.add_argument("--no-overlap", action="store_true", help="single stream everywhere (clean per-kernel profiles)")
     args = ap.parse_args()
@@ -99,8 +102,12 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     import torch.distributed as dist
-    if world > 1:
+    multi = world > 1 or args.force_dist
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.single_device:
             local_rank = 0
@@ -125,7 +132,7 @@ def main():
                 p.data.fill_(1.0)
     teacher.eval().requires_grad_(False)
     loss_fn = sda.DistillationLoss(temperature=2.0, alpha=0.5, inplace_grad=True)
-    reducer = ddp.attach(student) if world > 1 else None
+    reducer = ddp.attach(student) if multi else None
     batch = synthetic_batch(args.batch, args.seq_len, rank, dev)
 
     if args.no_overlap:
@@ -156,7 +163,7 @@ def main():
         return total, task, distill, teach
 
     def barrier():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -184,13 +191,13 @@ def main():
         prof_dt = time.perf_counter() - tp
         prof = ops.prof_end()
         student.overlap_dw = not args.no_overlap
-    if world > 1:
+    if multi:
         tmax = torch.tensor([dt], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax)
     losses = [float(x) for x in out]
     grad_sync_ok = None
-    if world > 1:  # after the all-reduce every rank must hold the same averaged gradient
+    if multi:  # after the all-reduce every rank must hold the same averaged gradient
         cs = student.flat_grad.float().abs().sum().double().reshape(1)
         cs = cs if args.backend == "nccl" else cs.cpu()
         lo, hi = cs.clone(), cs.clone()
@@ -256,7 +263,7 @@ def main():
             except Exception as e:  # never lose the GPU line to a host-side problem
                 res["cpu_baseline"] = {"value": None, "error": repr(e)}
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 
