@@ -95,6 +95,9 @@ def main():
                     help="run the N>1 code path (process group, bucket all-reduce, embedding-row exchange) even "
                          "with one rank: a one-GPU rehearsal of the RCCL calls")
     ap.add_argument("--serial-teacher", action="store_true", help="teacher forward on the student's stream (no overlap)")
+    ap.add_argument("--full-head", action="store_true",
+                    help="apply lm_head / top-K / loss to all B*T rows (default: only the rows the loss reads, as "
+                         "DistillationTrainer.compute_loss does on training steps)")
     ap.add_argument("--no-overlap", action="store_true", help="single stream everywhere (clean per-kernel profiles)")
     args = ap.parse_args()
 
@@ -140,25 +143,32 @@ def main():
         student.overlap_dw = False
     side = None if args.serial_teacher else torch.cuda.Stream(device=dev)
 
-    def teacher_topk():
-        t_logits = teacher(input_ids=batch["teacher_input_ids"],
-                           attention_mask=batch["teacher_attention_mask"]).logits           # train.py:60-69
+    def teacher_topk(rows):
+        t_logits = teacher(input_ids=batch["teacher_input_ids"], attention_mask=batch["teacher_attention_mask"],
+                           logit_rows=rows).logits                                          # train.py:60-69
         return ops.logsoftmax_topk(t_logits, args.top_k, VOCAB)                             # train.py:80-91
 
     def step(overlap=True):
+        # the same sequence as speech_distill_amd.trainer.DistillationTrainer.compute_loss on a training step
         student.zero_grad()
+        rows = row_labels = None
+        if not args.full_head:  # rows whose shifted label is not -100 (distillation_loss.py:31-45); one host sync
+            rows, row_labels = ops.loss_rows(batch["labels"])
         with torch.no_grad():
             if side is None or not overlap:
-                tv, ti = teacher_topk()
+                tv, ti = teacher_topk(rows)
             else:  # the frozen teacher is independent of the student: run it on a second HIP stream
                 side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(side):
-                    tv, ti = teacher_topk()
+                    tv, ti = teacher_topk(rows)
         logits = student(input_ids=batch["input_ids"], attention_mask=batch["attention_mask"],
-                         labels=batch["labels"]).logits                                     # train.py:54
+                         labels=batch["labels"], logit_rows=rows).logits                    # train.py:54
         if side is not None and overlap:
             torch.cuda.current_stream().wait_stream(side)
-        total, task, distill, teach = loss_fn(logits, batch["labels"], teacher_top_k_v=tv, teacher_top_k_i=ti)
+        if rows is None:
+            total, task, distill, teach = loss_fn(logits, batch["labels"], teacher_top_k_v=tv, teacher_top_k_i=ti)
+        else:
+            total, task, distill, teach = loss_fn.forward_rows(logits, row_labels, teacher_top_k_v=tv, teacher_top_k_i=ti)
         total.backward()                                                                    # HF trainer.py:1961
         return total, task, distill, teach
 

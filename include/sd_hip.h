@@ -98,6 +98,9 @@ int sd_swiglu_bwd(const void* dact, const void* gate_up, void* dgate_up, int M, 
 /* ---- embedding (HF:381) and its deterministic scatter-add backward (dE += scale * rows of dx) */
 int sd_embedding_fwd(const int64_t* ids, const void* E, void* x, int M, int H, int V, void* stream);
 int sd_embedding_bwd(const int64_t* ids, const void* dx, void* dE, int M, int H, int V, float scale, void* stream);
+/* dst [M,H] = 0, then dst[rows[i]] = src[i] (rows unique): un-compacts the gradient of the rows the head kept
+ * (inverse of the row gather sd_embedding_fwd(rows, table=x) ; distillation_loss.py:45 `x[valid]` run backwards) */
+int sd_rows_scatter(const void* src, const int64_t* rows, void* dst, int n, int M, int H, void* stream);
 
 /* ---- causal GQA flash attention, head_dim 128 (flash_attn via train.py:160,177; maths HF:185-207).
  * q [B*T, ldq] head hq at column hq*128; k, v likewise per kv head; o [B*T, ldo]; lse fp32 [B,Hq,T].
@@ -137,6 +140,16 @@ int sd_kdloss_bwd(const void* student_logits, const void* teacher_logits, const 
                   const int64_t* labels, const void* row_stats, const float* loss_out, const float* grad_total,
                   void* grad_logits, int B, int T, int V, int K, float temperature, float alpha, int dtype, void* stream);
 
+/* Same loss on rows the caller already shifted and selected (distillation_loss.py:31-45 done by the caller):
+ * student_logits [R,V], teacher_logits [R,V] or (top_k_v, top_k_i) [R,K], row_labels int64 [R] = the label each row
+ * predicts (-100 still masks a row); row_stats of sd_kdloss_stats_bytes(R,1). */
+int sd_kdloss_fwd_rows(const void* student_logits, const void* teacher_logits, const void* top_k_v, const void* top_k_i,
+                       const int64_t* row_labels, void* row_stats, float* loss_out, int R, int V, int K,
+                       float temperature, float alpha, int dtype, void* stream);
+int sd_kdloss_bwd_rows(const void* student_logits, const void* teacher_logits, const void* top_k_v, const void* top_k_i,
+                       const int64_t* row_labels, const void* row_stats, const float* loss_out, const float* grad_total,
+                       void* grad_logits, int R, int V, int K, float temperature, float alpha, int dtype, void* stream);
+
 /* ---- fused AdamW on bf16 params with bf16 state (HF Trainer default optimizer on the bf16 student,
  * train.py:174,331-354; quirk Q5) and the global grad-norm / clip (HF trainer max_grad_norm). */
 int sd_sumsq_bf16(const void* x, int64_t n, float* out_accum, void* stream);
@@ -173,6 +186,12 @@ int64_t sd_qwen3_bwd_scratch_bytes(const sd_qwen3_dims* d, int B, int T);
 int sd_qwen3_forward(const sd_qwen3_dims* d, const sd_qwen3_params* p, const int64_t* ids, const int32_t* kv_len,
                      const void* cos_tab, const void* sin_tab, void* acts, int64_t acts_bytes, void* logits, int B, int T,
                      int save_for_backward, void* stream);
+/* same, with the lm_head applied only to the rows listed in head_rows (int64 [n_head_rows], flat b*T+t indices,
+ * unique, device memory; NULL = all rows): logits is then bf16 [n_head_rows, V].  The training step needs only the
+ * rows whose shifted label is not -100 (distillation_loss.py:37-45); HF computes all of them (train.py:54-55). */
+int sd_qwen3_forward_rows(const sd_qwen3_dims* d, const sd_qwen3_params* p, const int64_t* ids, const int32_t* kv_len,
+                          const void* cos_tab, const void* sin_tab, void* acts, int64_t acts_bytes, void* logits,
+                          const int64_t* head_rows, int n_head_rows, int B, int T, int save_for_backward, void* stream);
 /* g: same structure as p but holding gradient buffers (bf16, same shapes); dlogits bf16 [B*T,V];
  * accumulate: 0 overwrite grads, 1 add to them (gradient accumulation).
  * on_grads_ready (nullable) is called ON THE HOST, from inside this call, each time the kernels that
@@ -193,6 +212,12 @@ int sd_qwen3_backward(const sd_qwen3_dims* d, const sd_qwen3_params* p, const sd
                       const int32_t* kv_len, const void* cos_tab, const void* sin_tab, void* acts, int64_t acts_bytes,
                       void* dlogits, void* scratch, int64_t scratch_bytes, int B, int T, int accumulate,
                       void* dx0_out, sd_stage_cb on_grads_ready, void* cb_user, void* side_stream, void* stream);
+/* same for a forward made by sd_qwen3_forward_rows with the same head_rows: dlogits is bf16 [n_head_rows, V] */
+int sd_qwen3_backward_rows(const sd_qwen3_dims* d, const sd_qwen3_params* p, const sd_qwen3_params* g, const int64_t* ids,
+                           const int32_t* kv_len, const void* cos_tab, const void* sin_tab, void* acts,
+                           int64_t acts_bytes, void* dlogits, const int64_t* head_rows, int n_head_rows, void* scratch,
+                           int64_t scratch_bytes, int B, int T, int accumulate, void* dx0_out,
+                           sd_stage_cb on_grads_ready, void* cb_user, void* side_stream, void* stream);
 
 /* ---- optional live timing (bench.py): HIP events around every launch, on the launch stream.
  * kinds index the arrays of sd_prof_end; work = algorithmic FLOPs (GEMM, attention) or bytes (others). */

@@ -75,6 +75,9 @@ PROTOTYPES = {
     "sd_kdloss_stats_bytes": (_i64, [_i, _i]),
     "sd_kdloss_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _i, _vp]),
     "sd_kdloss_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _i, _vp]),
+    "sd_kdloss_fwd_rows": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _vp]),
+    "sd_kdloss_bwd_rows": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _vp]),
+    "sd_rows_scatter": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "sd_sumsq_bf16": (_i, [_vp, _i64, _vp, _vp]),
     "sd_adamw_bf16": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _vp, _f, _vp]),
     "sd_prof_begin": (_i, []),
@@ -82,6 +85,10 @@ PROTOTYPES = {
     "sd_qwen3_acts_bytes": (_i64, [C.POINTER(Dims), _i, _i, _i]),
     "sd_qwen3_bwd_scratch_bytes": (_i64, [C.POINTER(Dims), _i, _i]),
     "sd_qwen3_forward": (_i, [C.POINTER(Dims), C.POINTER(Params), _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i, _i, _i, _vp]),
+    "sd_qwen3_forward_rows": (_i, [C.POINTER(Dims), C.POINTER(Params), _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i, _i, _i,
+                                   _i, _vp]),
+    "sd_qwen3_backward_rows": (_i, [C.POINTER(Dims), C.POINTER(Params), C.POINTER(Params), _vp, _vp, _vp, _vp, _vp, _i64,
+                                    _vp, _vp, _i, _vp, _i64, _i, _i, _i, _vp, STAGE_CB, _vp, _vp, _vp]),
     "sd_qwen3_backward": (_i, [C.POINTER(Dims), C.POINTER(Params), C.POINTER(Params), _vp, _vp, _vp, _vp, _vp, _i64,
                                _vp, _vp, _i64, _i, _i, _i, _vp, STAGE_CB, _vp, _vp, _vp]),
 }

@@ -327,6 +327,16 @@ __global__ __launch_bounds__(256) void embedding_fwd_kernel(const int64_t* __res
   for (int c = lane_id() * 8; c < H; c += 512) *(bf16x8*)(x + (long)row * H + c) = *(const bf16x8*)(E + id * H + c);
 }
 
+// dst[rows[i]] = src[i] for unique row indices (dst was zero-filled by the launcher).
+__global__ __launch_bounds__(256) void rows_scatter_kernel(const bf16* __restrict__ src, const int64_t* __restrict__ rows,
+                                                           bf16* __restrict__ dst, int n, int M, int H) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  const long r = rows[i];
+  if (r < 0 || r >= M) return;
+  for (int c = lane_id() * 8; c < H; c += 512) *(bf16x8*)(dst + r * H + c) = *(const bf16x8*)(src + (long)i * H + c);
+}
+
 // Deterministic scatter-add: the block of the FIRST token carrying an id sums every token row with
 // that id (fixed order) and adds the total to dE[id]; other blocks exit.  No atomics, no sort.
 __global__ __launch_bounds__(256) void embedding_bwd_kernel(const int64_t* __restrict__ ids, const bf16* __restrict__ dx,
@@ -524,6 +534,16 @@ extern "C" int sd_embedding_fwd(const int64_t* ids, const void* E, void* x, int 
   if (M <= 0 || (H & 7)) return SD_ERR_SHAPE;
   SdProfScope prof(SD_K_EMBED, 4.0 * M * H, ST);
   hipLaunchKernelGGL(embedding_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, ST, ids, (const bf16*)E, (bf16*)x, M, H, V);
+  SD_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int sd_rows_scatter(const void* src, const int64_t* rows, void* dst, int n, int M, int H, void* stream) {
+  if (n < 0 || M <= 0 || (H & 7)) return SD_ERR_SHAPE;
+  SdProfScope prof(SD_K_EMBED, 2.0 * M * H + 4.0 * n * H, ST);
+  if (hipMemsetAsync(dst, 0, (size_t)M * H * 2, ST) != hipSuccess) return SD_ERR_WORKSPACE;
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(rows_scatter_kernel, dim3((n + 3) / 4), dim3(256), 0, ST, (const bf16*)src, rows, (bf16*)dst, n, M, H);
   SD_CHECK_LAUNCH();
   return 0;
 }

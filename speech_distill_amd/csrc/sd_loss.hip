@@ -48,14 +48,19 @@ template <> struct Ld8<float> {
   }
 };
 
-// row -> (b, t); label / mask are taken at t+1 (the causal shift).
+// row -> (b, t); label / mask are taken at t+1 (the causal shift).  T == 0: the caller already selected and
+// shifted the rows (sd_kdloss_fwd_rows): label / mask are taken at `row` itself.
 SD_DEV bool row_valid(const int64_t* labels, const uint8_t* mask, int row, int T, long* y) {
-  const int t = row % T;
-  if (t == T - 1) return false;
-  const long lab = labels[row + 1];
+  int at = row;
+  if (T) {
+    const int t = row % T;
+    if (t == T - 1) return false;
+    at = row + 1;
+  }
+  const long lab = labels[at];
   *y = lab;
   if (lab == -100) return false;
-  if (mask && !mask[row + 1]) return false;
+  if (mask && !mask[at]) return false;
   return true;
 }
 
@@ -217,7 +222,7 @@ __global__ __launch_bounds__(NT) void kd_bwd_kernel(const T* S, const T* __restr
   const float go = grad_out ? grad_out[0] : 1.f;
   const float a1 = go * alpha / N;                       // * softmax(s)
   const float aT = go * (1.f - alpha) * temperature / N;  // * softmax(s/T)  and  * q
-  const long y = labels[row + 1];
+  const long y = labels[row + (Tlen ? 1 : 0)];
   const T* s = S + (long)row * V;
   const T* tl = Tl ? Tl + (long)row * V : nullptr;
   const bool sparse = (tl == nullptr);
@@ -276,7 +281,7 @@ __global__ __launch_bounds__(NT) void kd_bwd_kernel(const T* S, const T* __restr
 template <typename T>
 int run_fwd(const void* S, const void* Tl, const void* topv, const void* topi, const int64_t* labels, const uint8_t* mask,
             void* stats, float* out, int B, int Tlen, int V, int K, float temperature, float alpha, hipStream_t st) {
-  const int rows = B * Tlen;
+  const int rows = Tlen ? B * Tlen : B;  // Tlen == 0: B pre-selected rows
   SdProfScope prof(SD_K_LOSS_FWD, (double)rows * V * sizeof(T) * (Tl ? 2 : 1), st);
   hipLaunchKernelGGL((kd_fwd_kernel<T>), dim3(rows), dim3(NT), 0, st, (const T*)S, (const T*)Tl, (const _Float16*)topv,
                      (const int32_t*)topi, labels, mask, (RowStats*)stats, rows, Tlen, V, K, temperature);
@@ -291,7 +296,7 @@ template <typename T>
 int run_bwd(const void* S, const void* Tl, const void* topv, const void* topi, const int64_t* labels, const void* stats,
             const float* out, const float* go, void* G, int B, int Tlen, int V, int K, float temperature, float alpha,
             hipStream_t st) {
-  const int rows = B * Tlen;
+  const int rows = Tlen ? B * Tlen : B;
   SdProfScope prof(SD_K_LOSS_BWD, (double)rows * V * sizeof(T) * (Tl ? 3 : 2), st);
   hipLaunchKernelGGL((kd_bwd_kernel<T>), dim3(rows), dim3(NT), 0, st, (const T*)S, (const T*)Tl, (const _Float16*)topv,
                      (const int32_t*)topi, labels, (const RowStats*)stats, out, go, (T*)G, rows, Tlen, V, K, temperature,
@@ -301,7 +306,7 @@ int run_bwd(const void* S, const void* Tl, const void* topv, const void* topi, c
 }
 
 int check(const void* S, const void* Tl, const void* topv, const void* topi, int B, int Tlen, int V, int K, int dtype) {
-  if (B <= 0 || Tlen <= 0 || V <= 0) return SD_ERR_SHAPE;
+  if (B <= 0 || Tlen < 0 || V <= 0) return SD_ERR_SHAPE;
   if (V & 7) return SD_ERR_ALIGN;
   if ((uintptr_t)S & 15) return SD_ERR_ALIGN;
   if (dtype != SD_DTYPE_BF16 && dtype != SD_DTYPE_F32) return SD_ERR_UNSUPPORTED;
@@ -313,6 +318,30 @@ int check(const void* S, const void* Tl, const void* topv, const void* topi, int
 }  // namespace
 
 extern "C" int64_t sd_kdloss_stats_bytes(int B, int T) { return (int64_t)B * T * sizeof(RowStats); }
+
+extern "C" int sd_kdloss_fwd_rows(const void* student_logits, const void* teacher_logits, const void* top_k_v,
+                                  const void* top_k_i, const int64_t* row_labels, void* row_stats, float* loss_out, int R,
+                                  int V, int K, float temperature, float alpha, int dtype, void* stream) {
+  if (int e = check(student_logits, teacher_logits, top_k_v, top_k_i, R, 0, V, K, dtype)) return e;
+  if (dtype == SD_DTYPE_BF16)
+    return run_fwd<bf16>(student_logits, teacher_logits, top_k_v, top_k_i, row_labels, nullptr, row_stats, loss_out, R, 0,
+                         V, K, temperature, alpha, (hipStream_t)stream);
+  return run_fwd<float>(student_logits, teacher_logits, top_k_v, top_k_i, row_labels, nullptr, row_stats, loss_out, R, 0,
+                        V, K, temperature, alpha, (hipStream_t)stream);
+}
+
+extern "C" int sd_kdloss_bwd_rows(const void* student_logits, const void* teacher_logits, const void* top_k_v,
+                                  const void* top_k_i, const int64_t* row_labels, const void* row_stats,
+                                  const float* loss_out, const float* grad_total, void* grad_logits, int R, int V, int K,
+                                  float temperature, float alpha, int dtype, void* stream) {
+  if (int e = check(student_logits, teacher_logits, top_k_v, top_k_i, R, 0, V, K, dtype)) return e;
+  if ((uintptr_t)grad_logits & 15) return SD_ERR_ALIGN;
+  if (dtype == SD_DTYPE_BF16)
+    return run_bwd<bf16>(student_logits, teacher_logits, top_k_v, top_k_i, row_labels, row_stats, loss_out, grad_total,
+                         grad_logits, R, 0, V, K, temperature, alpha, (hipStream_t)stream);
+  return run_bwd<float>(student_logits, teacher_logits, top_k_v, top_k_i, row_labels, row_stats, loss_out, grad_total,
+                        grad_logits, R, 0, V, K, temperature, alpha, (hipStream_t)stream);
+}
 
 extern "C" int sd_kdloss_fwd(const void* student_logits, const void* teacher_logits, const void* top_k_v,
                              const void* top_k_i, const int64_t* labels, const uint8_t* speech_mask, void* row_stats,

@@ -23,7 +23,7 @@ struct Sizes {
     act = al((int64_t)M * I * 2);
   }
   int64_t per_layer() const { return 4 * x + 2 * rstd + qkv + qk + ao + lse + gu + act; }
-  int64_t tail() const { return 2 * x + rstd; }
+  int64_t tail() const { return 3 * x + rstd; }  // x_last, rstd_f, xn_f, xn_rows (head rows gathered)
 };
 
 struct LayerActs {
@@ -106,8 +106,17 @@ extern "C" int64_t sd_qwen3_bwd_scratch_bytes(const sd_qwen3_dims* d, int B, int
 extern "C" int sd_qwen3_forward(const sd_qwen3_dims* d, const sd_qwen3_params* p, const int64_t* ids,
                                 const int32_t* kv_len, const void* cos_tab, const void* sin_tab, void* acts,
                                 int64_t acts_bytes, void* logits, int B, int T, int save, void* stream) {
+  return sd_qwen3_forward_rows(d, p, ids, kv_len, cos_tab, sin_tab, acts, acts_bytes, logits, nullptr, 0, B, T, save,
+                               stream);
+}
+
+extern "C" int sd_qwen3_forward_rows(const sd_qwen3_dims* d, const sd_qwen3_params* p, const int64_t* ids,
+                                     const int32_t* kv_len, const void* cos_tab, const void* sin_tab, void* acts,
+                                     int64_t acts_bytes, void* logits, const int64_t* head_rows, int n_head_rows, int B,
+                                     int T, int save, void* stream) {
   if (d->head_dim != 128) return SD_ERR_UNSUPPORTED;
   if (B <= 0 || T <= 0) return SD_ERR_SHAPE;
+  if (head_rows && (n_head_rows <= 0 || n_head_rows > B * T)) return SD_ERR_SHAPE;
   Sizes s(d, B, T);
   if (acts_bytes < sd_qwen3_acts_bytes(d, B, T, save)) return SD_ERR_WORKSPACE;
   char* base = (char*)acts;
@@ -116,6 +125,7 @@ extern "C" int sd_qwen3_forward(const sd_qwen3_dims* d, const sd_qwen3_params* p
   char* x_last = tail;
   char* rstd_f = tail + s.x;
   char* xn_f = rstd_f + s.rstd;
+  char* xn_rows = xn_f + s.x;
   char* pong = base + s.per_layer();  // inference only
 
   LayerActs a0 = carve(s, base);
@@ -156,7 +166,14 @@ extern "C" int sd_qwen3_forward(const sd_qwen3_dims* d, const sd_qwen3_params* p
     x_cur = x_out;
   }
   RUN(sd_rmsnorm_fwd(x_last, p->final_norm, xn_f, (float*)rstd_f, s.M, s.h, d->eps, stream));
-  if (logits) RUN(sd_gemm_bf16(xn_f, p->lm_head, logits, nullptr, s.M, s.V, s.h, s.h, s.h, s.V, 0, 0, 0, stream));
+  if (logits && head_rows) {
+    // lm_head only for the rows the loss will read (HF computes all B*T rows, train.py:54-55; the rows whose shifted
+    // label is -100 never reach the loss, distillation_loss.py:37-45)
+    RUN(sd_embedding_fwd(head_rows, xn_f, xn_rows, n_head_rows, s.h, s.M, stream));
+    RUN(sd_gemm_bf16(xn_rows, p->lm_head, logits, nullptr, n_head_rows, s.V, s.h, s.h, s.h, s.V, 0, 0, 0, stream));
+  } else if (logits) {
+    RUN(sd_gemm_bf16(xn_f, p->lm_head, logits, nullptr, s.M, s.V, s.h, s.h, s.h, s.V, 0, 0, 0, stream));
+  }
   return 0;
 }
 
@@ -165,7 +182,18 @@ extern "C" int sd_qwen3_backward(const sd_qwen3_dims* d, const sd_qwen3_params* 
                                  void* acts, int64_t acts_bytes, void* dlogits, void* scratch, int64_t scratch_bytes, int B,
                                  int T, int accumulate, void* dx0_out, sd_stage_cb on_grads_ready, void* cb_user,
                                  void* side_stream, void* stream) {
+  return sd_qwen3_backward_rows(d, p, g, ids, kv_len, cos_tab, sin_tab, acts, acts_bytes, dlogits, nullptr, 0, scratch,
+                                scratch_bytes, B, T, accumulate, dx0_out, on_grads_ready, cb_user, side_stream, stream);
+}
+
+extern "C" int sd_qwen3_backward_rows(const sd_qwen3_dims* d, const sd_qwen3_params* p, const sd_qwen3_params* g,
+                                      const int64_t* ids, const int32_t* kv_len, const void* cos_tab, const void* sin_tab,
+                                      void* acts, int64_t acts_bytes, void* dlogits, const int64_t* head_rows,
+                                      int n_head_rows, void* scratch, int64_t scratch_bytes, int B, int T, int accumulate,
+                                      void* dx0_out, sd_stage_cb on_grads_ready, void* cb_user, void* side_stream,
+                                      void* stream) {
   if (d->head_dim != 128) return SD_ERR_UNSUPPORTED;
+  if (head_rows && (n_head_rows <= 0 || n_head_rows > B * T)) return SD_ERR_SHAPE;
   Sizes s(d, B, T);
   if (acts_bytes < sd_qwen3_acts_bytes(d, B, T, 1)) return SD_ERR_WORKSPACE;
   BwdScratch b(s, (char*)scratch);
@@ -176,6 +204,7 @@ extern "C" int sd_qwen3_backward(const sd_qwen3_dims* d, const sd_qwen3_params* 
   char* x_last = tail;
   char* rstd_f = tail + s.x;
   char* xn_f = rstd_f + s.rstd;
+  char* xn_rows = xn_f + s.x;
   const int acc = accumulate ? 1 : 0;
 #define ACC(ptr) (acc ? (const void*)(ptr) : (const void*)nullptr)
   // A/B switch for measurements: SD_OVERLAP_MASK bit0 lm_head dW, bit1 gain reduces, bit2 attention dQ (default all on)
@@ -189,11 +218,20 @@ extern "C" int sd_qwen3_backward(const sd_qwen3_dims* d, const sd_qwen3_params* 
 
   // lm_head: dxn = dlogits . W ; dW (+)= dlogits^T . xn_f
   SIGNAL(0);  // dlogits (produced on `stream` by the caller) is final: lm_head dW runs beside lm_head dX
-  RUN(sd_gemm_bf16(dlogits, xn_f, g->lm_head, ACC(g->lm_head), s.V, s.h, s.M, s.V, s.h, s.h, s.h, 1, 1,
-                   (ovl & 1) ? wstream : stream));
   int nsp = 1;
-  RUN(sd_gemm_bf16_splitk_partial(dlogits, p->lm_head, b.dxn, s.M, s.h, s.V, s.V, s.h, s.h, 0, 1, b.ws_splitk,
-                                  b.splitk_bytes, &nsp, stream));
+  if (head_rows) {
+    // dlogits holds only the n_head_rows rows the forward produced; every other row of d(xn_f) is zero
+    RUN(sd_gemm_bf16(dlogits, xn_rows, g->lm_head, ACC(g->lm_head), s.V, s.h, n_head_rows, s.V, s.h, s.h, s.h, 1, 1,
+                     (ovl & 1) ? wstream : stream));
+    RUN(sd_gemm_bf16_splitk(dlogits, p->lm_head, b.dx_b, nullptr, n_head_rows, s.h, s.V, s.V, s.h, s.h, 0, 0, 1,
+                            b.ws_splitk, b.splitk_bytes, stream));
+    RUN(sd_rows_scatter(b.dx_b, head_rows, b.dxn, n_head_rows, s.M, s.h, stream));
+  } else {
+    RUN(sd_gemm_bf16(dlogits, xn_f, g->lm_head, ACC(g->lm_head), s.V, s.h, s.M, s.V, s.h, s.h, s.h, 1, 1,
+                     (ovl & 1) ? wstream : stream));
+    RUN(sd_gemm_bf16_splitk_partial(dlogits, p->lm_head, b.dxn, s.M, s.h, s.V, s.V, s.h, s.h, 0, 1, b.ws_splitk,
+                                    b.splitk_bytes, &nsp, stream));
+  }
   if (g->embed != g->lm_head && !acc)
     if (hipMemsetAsync(g->embed, 0, (size_t)s.V * s.h * 2, (hipStream_t)stream) != hipSuccess) return SD_ERR_WORKSPACE;
   // the norm backward sums the split-K slabs itself (no separate reduce pass)

@@ -12,7 +12,7 @@ same ``ValueError`` when neither teacher form is given.  Differences, all docume
 import torch
 import torch.nn as nn
 
-from .ops import KDLossFn
+from .ops import KDLossFn, KDLossRowsFn
 
 
 class DistillationLoss(nn.Module):
@@ -35,4 +35,16 @@ class DistillationLoss(nn.Module):
         total, out = KDLossFn.apply(student_logits, labels, teacher_logits, teacher_top_k_v, teacher_top_k_i,
                                     speech_token_mask, self.temperature, self.alpha,
                                     self.inplace_grad and student_logits.requires_grad)
+        return total, out[1], out[2], out[3]
+
+    def forward_rows(self, student_logits, row_labels, teacher_logits=None, teacher_top_k_v=None, teacher_top_k_i=None):
+        """Same 4-tuple for rows already shifted and selected by ``ops.loss_rows`` (what distillation_loss.py:31-45
+        does with copies): ``student_logits`` [R,V], ``row_labels`` [R], teacher form [R,V] or ([R,K], [R,K])."""
+        if teacher_logits is None and (teacher_top_k_v is None or teacher_top_k_i is None):
+            raise ValueError("Either teacher_logits or top_k must be provided")
+        if teacher_logits is not None:
+            teacher_logits = teacher_logits.detach()
+        total, out = KDLossRowsFn.apply(student_logits.contiguous(), row_labels, teacher_logits, teacher_top_k_v,
+                                        teacher_top_k_i, self.temperature, self.alpha,
+                                        self.inplace_grad and student_logits.requires_grad)
         return total, out[1], out[2], out[3]

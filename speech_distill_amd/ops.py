@@ -239,6 +239,75 @@ class KDLossFn(torch.autograd.Function):
         return grad, None, None, None, None, None, None, None, None
 
 
+class KDLossRowsFn(torch.autograd.Function):
+    """The same loss on rows the caller has already shifted and selected (distillation_loss.py:31-45 done by the
+    caller): student_logits [R,V], row_labels [R], teacher_logits [R,V] or (top_v, top_i) [R,K]."""
+
+    @staticmethod
+    def forward(ctx, student_logits, row_labels, teacher_logits, top_v, top_i, temperature, alpha, inplace_grad):
+        s = _need(student_logits, None, "student_logits")
+        R, V = s.shape
+        dt = _dt(s)
+        lib = load_lib()
+        row_labels = _need(row_labels.to(torch.int64), torch.int64, "row_labels")
+        K = 0
+        if teacher_logits is not None:
+            teacher_logits = _need(teacher_logits.to(s.dtype), None, "teacher_logits")
+            if teacher_logits.shape != s.shape:
+                raise ValueError(f"teacher_logits {tuple(teacher_logits.shape)} != student_logits {tuple(s.shape)}")
+            top_v = top_i = None
+        elif top_v is not None and top_i is not None:
+            K = top_v.shape[-1]
+            top_v = top_v.to(device=s.device, dtype=torch.float16).contiguous()
+            top_i = top_i.to(device=s.device, dtype=torch.int32).contiguous()
+        else:
+            raise ValueError("Either teacher_logits or top_k must be provided")  # distillation_loss.py:120
+        stats = torch.empty(lib.sd_kdloss_stats_bytes(R, 1), dtype=torch.uint8, device=s.device)
+        out = torch.empty(8, dtype=torch.float32, device=s.device)
+        check(lib.sd_kdloss_fwd_rows(s.data_ptr(), _p(teacher_logits), _p(top_v), _p(top_i), row_labels.data_ptr(),
+                                     stats.data_ptr(), out.data_ptr(), R, V, K, float(temperature), float(alpha), dt,
+                                     _stream()), "sd_kdloss_fwd_rows")
+        ctx.save_for_backward(s, row_labels, teacher_logits, top_v, top_i, stats, out)
+        ctx.cfg = (R, V, K, float(temperature), float(alpha), dt, bool(inplace_grad))
+        ctx.mark_non_differentiable(out)
+        return out[0].clone(), out
+
+    @staticmethod
+    def backward(ctx, g_total, _g_out):
+        s, row_labels, teacher_logits, top_v, top_i, stats, out = ctx.saved_tensors
+        R, V, K, temperature, alpha, dt, inplace = ctx.cfg
+        grad = s if inplace else torch.empty_like(s)
+        go = g_total.to(torch.float32).reshape(1).contiguous()
+        check(load_lib().sd_kdloss_bwd_rows(s.data_ptr(), _p(teacher_logits), _p(top_v), _p(top_i), row_labels.data_ptr(),
+                                            stats.data_ptr(), out.data_ptr(), go.data_ptr(), grad.data_ptr(), R, V, K,
+                                            temperature, alpha, dt, _stream()), "sd_kdloss_bwd_rows")
+        return grad, None, None, None, None, None, None, None
+
+
+def loss_rows(labels, speech_mask=None):
+    """Flat indices b*T+t of the rows the loss reads, and the label each one predicts: position t < T-1 whose
+    NEXT label is not -100 (and whose next mask bit is set) -- distillation_loss.py:31-45.  One host sync (the
+    row count sizes the lm_head GEMMs)."""
+    B, T = labels.shape
+    nxt = torch.full_like(labels, -100)
+    nxt[:, :-1] = labels[:, 1:]
+    valid = nxt != -100
+    if speech_mask is not None:
+        m = torch.zeros_like(valid)
+        m[:, :-1] = speech_mask.to(labels.device)[:, 1:] != 0
+        valid &= m
+    rows = torch.nonzero(valid.reshape(-1)).reshape(-1)
+    return rows, nxt.reshape(-1)[rows]
+
+
+def rows_scatter(src, rows, M):
+    src = _need(src, torch.bfloat16, "src")
+    dst = torch.empty(M, src.shape[1], dtype=torch.bfloat16, device=src.device)
+    check(load_lib().sd_rows_scatter(src.data_ptr(), rows.data_ptr(), dst.data_ptr(), src.shape[0], M, src.shape[1],
+                                     _stream()), "sd_rows_scatter")
+    return dst
+
+
 # --------------------------------------------------------------------------------------- optimizer
 def sumsq(x, out):
     check(load_lib().sd_sumsq_bf16(x.data_ptr(), x.numel(), out.data_ptr(), _stream()), "sd_sumsq_bf16")

@@ -75,16 +75,16 @@ class CausalLMOutput(dict):
 
 class _DecoderFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, anchor, input_ids, kv_len, model):
-        logits, acts = model._run_forward(input_ids, kv_len, save=True)
-        ctx.model, ctx.acts, ctx.ids, ctx.kv_len = model, acts, input_ids, kv_len
+    def forward(ctx, anchor, input_ids, kv_len, model, rows):
+        logits, acts = model._run_forward(input_ids, kv_len, save=True, rows=rows)
+        ctx.model, ctx.acts, ctx.ids, ctx.kv_len, ctx.rows = model, acts, input_ids, kv_len, rows
         return logits
 
     @staticmethod
     def backward(ctx, dlogits):
-        ctx.model._run_backward(ctx.ids, ctx.kv_len, ctx.acts, dlogits)
+        ctx.model._run_backward(ctx.ids, ctx.kv_len, ctx.acts, dlogits, rows=ctx.rows)
         ctx.acts = None
-        return torch.zeros((), device=dlogits.device), None, None, None
+        return torch.zeros((), device=dlogits.device), None, None, None, None
 
 
 class HipQwen3ForCausalLM(nn.Module):
@@ -250,17 +250,21 @@ class HipQwen3ForCausalLM(nn.Module):
             self._rope[key] = rope_tables(T, device, self.dims.rope_theta)
         return self._rope[key]
 
-    def _run_forward(self, input_ids, kv_len, save):
+    def _run_forward(self, input_ids, kv_len, save, rows=None):
         lib = load_lib()
         B, T = input_ids.shape
         dev = input_ids.device
         cos, sin = self._tables(T, dev)
         nbytes = lib.sd_qwen3_acts_bytes(C.byref(self._cdims), B, T, int(save))
         acts = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        logits = torch.empty(B, T, self.dims.vocab_size, dtype=torch.bfloat16, device=dev)
-        check(lib.sd_qwen3_forward(C.byref(self._cdims), C.byref(self._cparams), input_ids.data_ptr(), _p(kv_len),
-                                   cos.data_ptr(), sin.data_ptr(), acts.data_ptr(), nbytes, logits.data_ptr(), B, T,
-                                   int(save), _stream()), "sd_qwen3_forward")
+        if rows is None:
+            logits = torch.empty(B, T, self.dims.vocab_size, dtype=torch.bfloat16, device=dev)
+        else:
+            logits = torch.empty(rows.numel(), self.dims.vocab_size, dtype=torch.bfloat16, device=dev)
+        check(lib.sd_qwen3_forward_rows(C.byref(self._cdims), C.byref(self._cparams), input_ids.data_ptr(), _p(kv_len),
+                                        cos.data_ptr(), sin.data_ptr(), acts.data_ptr(), nbytes, logits.data_ptr(),
+                                        _p(rows), 0 if rows is None else rows.numel(), B, T, int(save), _stream()),
+              "sd_qwen3_forward_rows")
         return logits, acts
 
     def _ensure_grads(self):
@@ -276,7 +280,7 @@ class HipQwen3ForCausalLM(nn.Module):
             self._grads_live = True
         return accumulate
 
-    def _run_backward(self, input_ids, kv_len, acts, dlogits):
+    def _run_backward(self, input_ids, kv_len, acts, dlogits, rows=None):
         lib = load_lib()
         B, T = input_ids.shape
         accumulate = self._ensure_grads()
@@ -296,11 +300,13 @@ class HipQwen3ForCausalLM(nn.Module):
         scratch = torch.empty(sbytes, dtype=torch.uint8, device=input_ids.device)
         user_cb = self._stage_cb
         cb = _lib.STAGE_CB((lambda stage, _u: user_cb(stage)) if user_cb else 0)
-        check(lib.sd_qwen3_backward(C.byref(self._cdims), C.byref(self._cparams), C.byref(self._cgrads),
-                                    input_ids.data_ptr(), _p(kv_len), cos.data_ptr(), sin.data_ptr(), acts.data_ptr(),
-                                    acts.numel(), dlogits.data_ptr(), scratch.data_ptr(), sbytes, B, T, int(accumulate),
-                                    _p(dx0), cb, None, self._side_stream_ptr(input_ids.device), _stream()),
-              "sd_qwen3_backward")
+        check(lib.sd_qwen3_backward_rows(C.byref(self._cdims), C.byref(self._cparams), C.byref(self._cgrads),
+                                         input_ids.data_ptr(), _p(kv_len), cos.data_ptr(), sin.data_ptr(),
+                                         acts.data_ptr(), acts.numel(), dlogits.data_ptr(), _p(rows),
+                                         0 if rows is None else rows.numel(), scratch.data_ptr(), sbytes, B, T,
+                                         int(accumulate), _p(dx0), cb, None, self._side_stream_ptr(input_ids.device),
+                                         _stream()),
+              "sd_qwen3_backward_rows")
         if red is not None:
             red.finish()
 
@@ -312,17 +318,24 @@ class HipQwen3ForCausalLM(nn.Module):
             self._side_stream = torch.cuda.Stream(device=device)
         return self._side_stream.cuda_stream
 
-    def forward(self, input_ids=None, attention_mask=None, labels=None, **kwargs):
+    def forward(self, input_ids=None, attention_mask=None, labels=None, logit_rows=None, **kwargs):
         """Returns an object with ``.logits`` [B,T,V] (bf16).  ``labels`` is accepted and ignored: the
-        reference leaves it in ``inputs`` at train.py:54, which only makes HF compute an unused CE."""
+        reference leaves it in ``inputs`` at train.py:54, which only makes HF compute an unused CE.
+        ``logit_rows`` (int64 [R], flat b*T+t indices, unique): apply the lm_head to those rows only and return
+        ``.logits`` [R,V] -- the training step passes the rows the loss reads (``ops.loss_rows``)."""
         ids = _need(input_ids.to(torch.int64), torch.int64, "input_ids")
+        rows = None
+        if logit_rows is not None:
+            rows = _need(logit_rows.to(device=ids.device, dtype=torch.int64), torch.int64, "logit_rows")
+            if rows.dim() != 1 or rows.numel() == 0 or rows.numel() > ids.numel():
+                raise ValueError("logit_rows must be a non-empty 1-D tensor of at most B*T row indices")
         kv_len = None
         if attention_mask is not None:
             kv_len = attention_mask.to(ids.device).sum(-1).to(torch.int32).contiguous()  # right padding (data.py:292-327)
         if torch.is_grad_enabled() and any(p.requires_grad for p in self._params.values()):
-            logits = _DecoderFn.apply(self._anchor, ids, kv_len, self)
+            logits = _DecoderFn.apply(self._anchor, ids, kv_len, self, rows)
         else:
-            logits, _ = self._run_forward(ids, kv_len, save=False)
+            logits, _ = self._run_forward(ids, kv_len, save=False, rows=rows)
         return CausalLMOutput(logits=logits)
 
     def zero_grad(self, set_to_none: bool = True):

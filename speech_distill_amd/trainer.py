@@ -32,15 +32,25 @@ class DistillationTrainer(Trainer):
         # stream beside the student forward (+4.5 % step throughput on MI355X); results are identical.
         self.overlap_teacher = True
         self._teacher_stream = None
+        # Training steps apply both lm_heads, the top-K and the loss only to the rows the loss reads (positions whose
+        # NEXT label is not -100, distillation_loss.py:31-45) instead of computing all B*T rows and masking them
+        # afterwards; loss and gradients are the same, the head is ~(masked fraction) cheaper.  Needs one host sync
+        # per step for the row count.  Off: the full [B,T,V] path; return_outputs=True always uses the full path.
+        self.compact_head = True
 
-    def _teacher_pass(self, inputs, teacher_input_ids, teacher_attention_mask, vocab_size):
-        """train.py:60-94: teacher no-grad forward, then on-the-fly top-K unless quantized / top_k <= 0."""
+    def _teacher_pass(self, inputs, teacher_input_ids, teacher_attention_mask, vocab_size, rows=None):
+        """train.py:60-94: teacher no-grad forward, then on-the-fly top-K unless quantized / top_k <= 0.
+        ``rows``: only those flat rows of the logits are produced (our own teacher) or kept (any other module)."""
         with torch.no_grad():
+            extra = {"logit_rows": rows} if rows is not None and isinstance(self.teacher_model, HipQwen3ForCausalLM) else {}
             if teacher_input_ids is not None:
-                teacher_outputs = self.teacher_model(input_ids=teacher_input_ids, attention_mask=teacher_attention_mask)
+                teacher_outputs = self.teacher_model(input_ids=teacher_input_ids, attention_mask=teacher_attention_mask,
+                                                     **extra)
             else:
-                teacher_outputs = self.teacher_model(**{k: v for k, v in inputs.items() if k != "labels"})
+                teacher_outputs = self.teacher_model(**{k: v for k, v in inputs.items() if k != "labels"}, **extra)
             teacher_logits = teacher_outputs.logits
+            if rows is not None and not extra:
+                teacher_logits = teacher_logits.reshape(-1, teacher_logits.size(-1))[rows]
             if not self.is_quantized_teacher and self.top_k > 0:
                 v, i = self._extract_topk(teacher_logits, self.top_k, vocab_size)
                 return None, v, i
@@ -57,6 +67,13 @@ class DistillationTrainer(Trainer):
         vocab = getattr(getattr(model, "dims", None), "vocab_size", None)  # only our own model type is overlapped
         side = None
         ids = inputs.get("input_ids")
+        rows = row_labels = None
+        lab = inputs.get("labels")
+        if (self.compact_head and not return_outputs and isinstance(model, HipQwen3ForCausalLM) and lab is not None
+                and lab.is_cuda and isinstance(self.distill_loss_fn, DistillationLoss)):
+            rows, row_labels = ops.loss_rows(lab, speech_mask)
+            if rows.numel() == 0:  # N == 0: the full path returns the reference's zeros (distillation_loss.py:47-53)
+                rows = row_labels = None
         if (need_teacher and self.overlap_teacher and vocab is not None and ids is not None and ids.is_cuda
                 and isinstance(self.teacher_model, HipQwen3ForCausalLM)):
             if self._teacher_stream is None:
@@ -65,9 +82,13 @@ class DistillationTrainer(Trainer):
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 teacher_logits, teacher_top_k_v, teacher_top_k_i = self._teacher_pass(
-                    inputs, teacher_input_ids, teacher_attention_mask, vocab)
+                    inputs, teacher_input_ids, teacher_attention_mask, vocab, rows)
+        elif rows is not None and teacher_top_k_v is not None:  # pre-extracted top-K: keep the same rows
+            dev = lab.device
+            teacher_top_k_v = teacher_top_k_v.to(dev).reshape(-1, teacher_top_k_v.size(-1))[rows]
+            teacher_top_k_i = teacher_top_k_i.to(dev).reshape(-1, teacher_top_k_i.size(-1))[rows]
 
-        outputs = model(**inputs)  # train.py:54
+        outputs = model(**inputs) if rows is None else model(**inputs, logit_rows=rows)  # train.py:54
         student_logits = outputs.logits
         labels = inputs.pop("labels", None)
 
@@ -77,14 +98,19 @@ class DistillationTrainer(Trainer):
             teacher_logits_local = teacher_logits
         elif need_teacher:  # reference order: student first, then teacher (train.py:60-94)
             teacher_logits_local, teacher_top_k_v, teacher_top_k_i = self._teacher_pass(
-                inputs, teacher_input_ids, teacher_attention_mask, student_logits.size(-1))
+                inputs, teacher_input_ids, teacher_attention_mask, student_logits.size(-1), rows)
         teacher_logits = teacher_logits_local
 
         if isinstance(self.distill_loss_fn, DistillationLoss):
             self.distill_loss_fn.inplace_grad = (not return_outputs) and isinstance(model, HipQwen3ForCausalLM)
-        loss, task_loss, distill_loss, teacher_loss = self.distill_loss_fn(
-            student_logits=student_logits, labels=labels, teacher_logits=teacher_logits,
-            teacher_top_k_v=teacher_top_k_v, teacher_top_k_i=teacher_top_k_i, speech_token_mask=speech_mask)
+        if rows is not None:
+            loss, task_loss, distill_loss, teacher_loss = self.distill_loss_fn.forward_rows(
+                student_logits, row_labels, teacher_logits=teacher_logits, teacher_top_k_v=teacher_top_k_v,
+                teacher_top_k_i=teacher_top_k_i)
+        else:
+            loss, task_loss, distill_loss, teacher_loss = self.distill_loss_fn(
+                student_logits=student_logits, labels=labels, teacher_logits=teacher_logits,
+                teacher_top_k_v=teacher_top_k_v, teacher_top_k_i=teacher_top_k_i, speech_token_mask=speech_mask)
 
         if self.state.global_step % self.args.logging_steps == 0:  # train.py:107-114
             # one device->host sync for the three scalars instead of three .item() calls

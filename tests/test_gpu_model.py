@@ -140,11 +140,14 @@ def _trainer(sda, top_k, epochs=1, lr=1e-3):
     return tr, student, coll, feats, z
 
 
+@pytest.mark.parametrize("compact", [True, False])
 @pytest.mark.parametrize("mode,top_k", [("sparse", 16), ("dense", 0)])
-def test_c1_compute_loss_matches_reference(sda, mode, top_k):
+def test_c1_compute_loss_matches_reference(sda, mode, top_k, compact):
     """BASELINE config 1: DistillationTrainer.compute_loss on the two fixed micro-batches vs the reference's
-    own DistillationTrainer (fp32 CPU) -- loss, the three logged sub-losses, gradient norms and directions."""
+    own DistillationTrainer (fp32 CPU) -- loss, the three logged sub-losses, gradient norms and directions;
+    with the head applied to the loss rows only (the training default) and to all B*T rows."""
     tr, student, coll, feats, z = _trainer(sda, top_k)
+    tr.compact_head = compact
     logged = []
     tr.log = lambda d, *a, **k: logged.append(dict(d))
     for mb in range(2):
@@ -167,6 +170,57 @@ def test_c1_compute_loss_matches_reference(sda, mode, top_k):
             c = _cos(student._params[name].grad, torch.from_numpy(z[f"{mode}_mb{mb}_{key}"]))
             record(f"c1_{mode}_mb{mb}_cos", param=name, cos=c)
             assert c >= 0.99, f"{mode} mb{mb} {name}: cosine {c}"
+
+
+def test_head_rows_equal_full_head(sda):
+    """lm_head + loss on the loss rows only == the full [B,T,V] path: same logits rows bit for bit, same loss,
+    same gradients (the dropped rows have zero gradient), on a ragged batch with a masked prefix."""
+    from speech_distill_amd import ops
+    from speech_distill_amd.distillation_loss import DistillationLoss
+    torch.manual_seed(3)
+    dims = sda.Qwen3Dims(vocab_size=1000, hidden_size=256, intermediate_size=512, num_hidden_layers=2,
+                         num_attention_heads=4, num_key_value_heads=2, head_dim=128, rms_norm_eps=1e-6, rope_theta=1e6,
+                         tie_word_embeddings=True)
+    m = sda.HipQwen3ForCausalLM(dims, device=dev(), init_std=0.05, seed=5)
+    B, T, K = 3, 70, 16
+    ids = torch.randint(0, 1000, (B, T), device=dev())
+    am = torch.ones(B, T, dtype=torch.int64, device=dev())
+    am[1, 50:] = 0
+    labels = ids.clone()
+    labels[:, :17] = -100
+    labels[am == 0] = -100
+    labels[2, 33] = -100
+    tv, ti = ops.logsoftmax_topk(torch.randn(B, T, 1000, device=dev()).bfloat16(), K)
+    loss_fn = DistillationLoss(2.0, 0.5)
+    rows, row_labels = ops.loss_rows(labels)
+    assert rows.numel() == int(((labels[:, 1:] != -100)).sum())
+
+    m.zero_grad()
+    full = m(input_ids=ids, attention_mask=am).logits
+    t_full = loss_fn(full, labels, teacher_top_k_v=tv, teacher_top_k_i=ti)
+    t_full[0].backward()
+    g_full = m.flat_grad.clone()
+
+    m.zero_grad()
+    part = m(input_ids=ids, attention_mask=am, logit_rows=rows).logits
+    assert part.shape == (rows.numel(), 1000)
+    assert torch.equal(part.detach(), full.detach().reshape(-1, 1000)[rows])
+    t_rows = loss_fn.forward_rows(part, row_labels, teacher_top_k_v=tv.reshape(-1, K)[rows],
+                                  teacher_top_k_i=ti.reshape(-1, K)[rows])
+    t_rows[0].backward()
+    g_rows = m.flat_grad.clone()
+    for a, b in zip(t_full, t_rows):
+        assert abs(float(a) - float(b)) <= 1e-6 * max(1.0, abs(float(a)))
+    c = _cos(g_rows, g_full)
+    rel = float((g_rows.double() - g_full.double()).norm() / g_full.double().norm())
+    record("head_rows_vs_full", rows=int(rows.numel()), of=B * T, cos=c, rel=rel)
+    assert c > 0.99999 and rel < 5e-3
+
+    with torch.no_grad():  # inference path (the frozen teacher)
+        part_nograd = m(input_ids=ids, attention_mask=am, logit_rows=rows).logits
+    assert torch.equal(part_nograd, part.detach())
+    with pytest.raises(ValueError):
+        m(input_ids=ids, logit_rows=rows[:0])
 
 
 def test_c1_real_trainer_loop_tracks_reference(sda):
