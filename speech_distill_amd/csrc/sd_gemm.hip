@@ -23,6 +23,7 @@
 // as fp32 and written out in full 16-byte row pieces with the epilogue fused (+ residual / accumulate).  Split-K
 // (contraction over the vocabulary): every K slice writes an fp32 slab; a reduce kernel -- or the consumer itself
 // (sd_rmsnorm_bwd_slabs) -- sums the slabs in a fixed order.
+#include <stdlib.h>
 #include "sd_common.cuh"
 #include "../../include/sd_hip.h"
 #include "sd_prof.h"
@@ -267,6 +268,21 @@ SD_DEV void write_out(const float* cs, bf16* C, const EpiPre<EPI, BM, NTHR>& pre
 }
 
 // EPI: 0 = bf16 out, 1 = bf16 out + residual, 2 = fp32 slab out (split-K)
+// Tile order inside the launch.  Workgroups that are resident together on one XCD (32 CUs behind one 4 MiB L2) should
+// share operand panels: with the plain column-major order an XCD's 32 consecutive tiles are 32 row tiles of ONE column
+// (for BM = 64: 272 KiB of unique operand bytes per K-step, L2 hit 65 %); walking `group_m` row tiles down, then
+// across all columns, makes them a group_m x (32/group_m) block (8 x 4: 128 KiB, hit 83 %).  The kernels are bound
+// by the L2 -> LDS rate (45-48 GB/s per CU at every tile shape), so the misses that go to the Infinity Cache count.
+SD_DEV void tile_coords(int tile, int tiles_m, int tiles_n, int group_m, int& tm, int& tn) {
+  const int per_group = group_m * tiles_n;
+  const int g = tile / per_group;
+  const int r = tile - g * per_group;
+  const int g0 = g * group_m;
+  const int gh = min(group_m, tiles_m - g0);
+  tn = r / gh;
+  tm = g0 + (r - tn * gh);
+}
+
 // NST-deep LDS ring: tile t+NST-1 is issued while tile t is computed; the wait for tile t is a COUNTED
 // s_waitcnt vmcnt that leaves the NST-2 younger tiles in flight across the (raw) barrier.  Tiles past
 // the end of K are still issued (their lanes read the zero page), which keeps the count uniform.
@@ -274,7 +290,7 @@ template <int BM, int NST, bool TA, bool TB, int EPI, bool FAST>
 __global__ __launch_bounds__(BM == 256 ? 512 : 256, (BM == 256 ? 2 : (NST * (BM + 128) * 128 <= 80 * 1024 ? 2 : 1))) void gemm_bf16_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B, bf16* C,
                                                         const bf16* R, float* __restrict__ slabs, int M, int N, int K,
                                                         long lda, long ldb, long ldc, long ldr, int tiles_m, int tiles_n,
-                                                        int k_tiles_per_split, EpiArgs ea) {
+                                                        int k_tiles_per_split, int group_m, EpiArgs ea) {
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
   constexpr int NW = (BM == 256) ? 8 : 4;          // waves: (NW/2) along M x 2 along N
   constexpr int NTHR = NW * 64;
@@ -288,7 +304,8 @@ __global__ __launch_bounds__(BM == 256 ? 512 : 256, (BM == 256 ? 2 : (NST * (BM 
   const int w = wave_id_uniform();
   const int wm = w >> 1, wn = w & 1;
   const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-  const int tm = tile % tiles_m, tn = tile / tiles_m;
+  int tm, tn;
+  tile_coords(tile, tiles_m, tiles_n, group_m, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
 
   EpiPre<EPI, BM, NTHR> pre;
@@ -397,7 +414,7 @@ template <bool TA, bool TB, int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_stag_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B, bf16* C,
                                                            const bf16* R, float* __restrict__ slabs, int M, int N, int K,
                                                            long lda, long ldb, long ldc, long ldr, int tiles_m,
-                                                           int tiles_n, int k_tiles_per_split, EpiArgs ea) {
+                                                           int tiles_n, int k_tiles_per_split, int group_m, EpiArgs ea) {
   constexpr int BM = 256, NW = 8, NST = 3;
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;  // 48 KiB
   constexpr int LOADS = (BM + BN) / (8 * NW);                                             // 6 per wave per tile
@@ -407,7 +424,8 @@ __global__ __launch_bounds__(512, 2) void gemm_stag_kernel(const bf16* __restric
   const int wm = w >> 1, wn = w & 1;
   const int half = w >> 2;  // waves 0-3 / 4-7: one of each per SIMD
   const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-  const int tm = tile % tiles_m, tn = tile / tiles_m;
+  int tm, tn;
+  tile_coords(tile, tiles_m, tiles_n, group_m, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
 
   EpiPre<EPI, 256, 512> pre;
@@ -501,6 +519,143 @@ __global__ __launch_bounds__(512, 2) void gemm_stag_kernel(const bf16* __restric
   write_out<EPI, 256, 512>(cs, C, pre, slabs, ea, M, N, ldc, m0, n0, tn);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// K-split staggered 64x128x64 kernel (8 waves) for GEMMs with few output tiles and a long K (N = hidden: o / down
+// forward, every dX; 128-256 tiles of 64x128 on 256 CUs).  With one 4-wave workgroup per CU there is one wave per
+// SIMD and its DMA issue, LDS reads and MFMAs run back to back (~1 270 cycles per K-step for 256 cycles of MFMA).
+// Here both 4-wave halves work on the SAME C tile: half h takes the K-tiles kt0 + 2t + h through its own 3-stage
+// ring (2 x 3 x 24 KiB), the halves run one phase apart exactly as in gemm_stag_kernel (same hazard argument, per
+// half), and the two partial accumulators are added through LDS before the common epilogue (fixed order:
+// deterministic).
+template <bool TA, bool TB, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_ks_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B, bf16* C,
+                                                         const bf16* R, float* __restrict__ slabs, int M, int N, int K,
+                                                         long lda, long ldb, long ldc, long ldr, int tiles_m, int tiles_n,
+                                                         int k_tiles_per_split, int group_m, EpiArgs ea) {
+  constexpr int BM = 64, NWH = 4, NST = 3;
+  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;  // 24 KiB
+  constexpr int LOADS = (BM + BN) / (8 * NWH);                                            // 6 per wave per tile
+  __shared__ __attribute__((aligned(16))) char smem[2 * NST * STAGE];                     // 144 KiB
+  const int lane = lane_id();
+  const int w = wave_id_uniform();
+  const int half = w >> 2, wh = w & 3;  // waves 0-3 / 4-7: one of each per SIMD
+  const int wm = wh >> 1, wn = wh & 1;
+  const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  int tm, tn;
+  tile_coords(tile, tiles_m, tiles_n, group_m, tm, tn);
+  const int m0 = tm * BM, n0 = tn * BN;
+  char* ring = smem + half * (NST * STAGE);
+
+  EpiPre<EPI, 64, 512> pre;
+  epi_preload<EPI, 64, 512>(pre, R, ea, M, N, ldr, m0, n0, tn);
+
+  f32x4 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int kt_all = (K + BK - 1) / BK;
+  const int kt0 = blockIdx.y * k_tiles_per_split;
+  const int kt1 = min(kt_all, kt0 + k_tiles_per_split);
+  const int nk = kt1 - kt0;
+  const int nkh = (nk + 1) >> 1;      // iterations of both halves
+  const int mine = (nk - half + 1) >> 1;  // K-tiles this half really owns (half 1 has one fewer when nk is odd)
+  FastStage<TA, BM, NWH> fa;
+  FastStage<TB, BN, NWH> fb;
+  fa.init(A, lda, m0, (unsigned)((TA ? ((long)(K - 1) * lda + M) : ((long)(M - 1) * lda + K)) * 2), wh, lane);
+  fb.init(B, ldb, n0, (unsigned)((TB ? ((long)(K - 1) * ldb + N) : ((long)(N - 1) * ldb + K)) * 2), wh, lane);
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    fa.issue((kt0 + 2 * s + half) * BK, ring + s * STAGE, wh);
+    fb.issue((kt0 + 2 * s + half) * BK, ring + s * STAGE + A_BYTES, wh);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  if (half == 1) __builtin_amdgcn_s_barrier();  // second half runs one phase behind
+
+  int cur_i = 0, nxt_i = 2;
+  for (int t = 0; t < nkh; ++t) {
+    // ---- LOAD(t)
+    {
+      char* nxt = ring + nxt_i * STAGE;
+      fa.issue((kt0 + 2 * (t + 2) + half) * BK, nxt, wh);
+      fb.issue((kt0 + 2 * (t + 2) + half) * BK, nxt + A_BYTES, wh);
+    }
+    const char* cur = ring + cur_i * STAGE;
+    bf16x8 af[2][2], bfr[2][4];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      if constexpr (TA) {
+        load_frags_tr<BM, 2>(cur, wm * 32, kk, lane, af[kk]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) af[kk][i] = load_frag<TA, BM>(cur, wm * 32 + i * 16, kk, lane);
+      }
+      if constexpr (TB) {
+        load_frags_tr<BN, 4>(cur + A_BYTES, wn * 64, kk, lane, bfr[kk]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bfr[kk][j] = load_frag<TB, BN>(cur + A_BYTES, wn * 64 + j * 16, kk, lane);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- COMPUTE(t): the tile past the end of an odd K range (half 1) holds foreign data and is skipped
+    if (t < mine) {
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(bfr[kk][j], af[kk][i], acc[i][j]);
+      __builtin_amdgcn_s_setprio(0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    cur_i = (cur_i == 2) ? 0 : cur_i + 1;
+    nxt_i = (nxt_i == 2) ? 0 : nxt_i + 1;
+  }
+  if (half == 0) __builtin_amdgcn_s_barrier();  // re-align the halves
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // half 1 parks its partial sums in LDS, half 0 adds them (same lane -> same address) and stores the total
+  float* cs = (float*)smem;  // [64][128] fp32
+  if (half == 1) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = wm * 32 + i * 16 + (lane & 15);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int cidx = wn * 16 + j * 4 + (lane >> 4);
+        *(f32x4*)(cs + m * 128 + ((cidx ^ (m & 15)) << 2)) = acc[i][j];
+      }
+    }
+  }
+  __syncthreads();
+  if (half == 0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = wm * 32 + i * 16 + (lane & 15);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int cidx = wn * 16 + j * 4 + (lane >> 4);
+        f32x4* p = (f32x4*)(cs + m * 128 + ((cidx ^ (m & 15)) << 2));
+        *p = acc[i][j] + *p;
+      }
+    }
+  }
+  __syncthreads();
+  write_out<EPI, 64, 512>(cs, C, pre, slabs, ea, M, N, ldc, m0, n0, tn);
+}
+
 // C = sum_s slab[s] (+ R), fixed order
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slabs, bf16* C, const bf16* R, int M,
                                                             int N, long ldc, long ldr, int splits) {
@@ -536,27 +691,34 @@ int launch(const void* A, const void* B, void* C, const void* R, float* slabs, i
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   const int kt_all = (K + BK - 1) / BK;
   const int per = (kt_all + splits - 1) / splits;
-  dim3 grid(tiles_m * tiles_n, splits), block(BM == 256 ? 512 : 256);
+  dim3 grid(tiles_m * tiles_n, splits), block((BM == 256 || (BM == 64 && NST == 9)) ? 512 : 256);
   // descriptor-based staging needs every k >= K to read as zero in at least one operand (transposed
   // operands get that from the hardware range check; two K-contiguous ones need K % 64 == 0) and 31-bit offsets
   const long bytes_a = (TA ? ((long)(K - 1) * lda + M) : ((long)(M - 1) * lda + K)) * 2;
   const long bytes_b = (TB ? ((long)(K - 1) * ldb + N) : ((long)(N - 1) * ldb + K)) * 2;
-  const long span = ((long)kt_all + 4) * BK * 2 * (TA ? lda : 1) + bytes_a;
-  const long span_b = ((long)kt_all + 4) * BK * 2 * (TB ? ldb : 1) + bytes_b;
+  const long span = ((long)kt_all + 6) * BK * 2 * (TA ? lda : 1) + bytes_a;
+  const long span_b = ((long)kt_all + 6) * BK * 2 * (TB ? ldb : 1) + bytes_b;
+  static const int gm_env = getenv("SD_GEMM_GROUP_M") ? atoi(getenv("SD_GEMM_GROUP_M")) : 0;  // A/B measurements
+  int gm = gm_env > 0 ? gm_env : (BM == 256 ? 4 : 8);
+  if (gm > tiles_m) gm = tiles_m;
   const bool fast = !g_no_fast_stage && (TA || TB || (K % BK) == 0) && span < 0x7fffffffL && span_b < 0x7fffffffL;
 #define SD_GEMM_GO(EPI)                                                                                              \
   do {                                                                                                               \
     if constexpr (BM == 256 && NST == 9) {                                                                           \
       hipLaunchKernelGGL((gemm_stag_kernel<TA, TB, EPI>), grid, block, 0, st, (const bf16*)A, (const bf16*)B,          \
-                         (bf16*)C, (const bf16*)R, slabs, M, N, K, lda, ldb, ldc, ldr, tiles_m, tiles_n, per, ea);     \
+                         (bf16*)C, (const bf16*)R, slabs, M, N, K, lda, ldb, ldc, ldr, tiles_m, tiles_n, per, gm, ea); \
+    } else if constexpr (BM == 64 && NST == 9) {                                                                     \
+      hipLaunchKernelGGL((gemm_ks_kernel<TA, TB, (EPI >= 3 ? 0 : EPI)>), grid, block, 0, st, (const bf16*)A,           \
+                         (const bf16*)B, (bf16*)C, (const bf16*)R, slabs, M, N, K, lda, ldb, ldc, ldr, tiles_m,        \
+                         tiles_n, per, gm, ea);                                                                      \
     } else if (fast || EPI >= 3)                                                                                     \
       hipLaunchKernelGGL((gemm_bf16_kernel<BM, (NST == 9 ? 3 : NST), TA, TB, EPI, true>), grid, block, 0, st,          \
                          (const bf16*)A, (const bf16*)B, (bf16*)C, (const bf16*)R, slabs, M, N, K, lda, ldb, ldc, ldr, \
-                         tiles_m, tiles_n, per, ea);                                                                 \
+                         tiles_m, tiles_n, per, gm, ea);                                                             \
     else                                                                                                             \
       hipLaunchKernelGGL((gemm_bf16_kernel<BM, (NST == 9 ? 3 : NST), TA, TB, (EPI >= 3 ? 0 : EPI), false>), grid,      \
                          block, 0, st, (const bf16*)A, (const bf16*)B, (bf16*)C, (const bf16*)R, slabs, M, N, K, lda,  \
-                         ldb, ldc, ldr, tiles_m, tiles_n, per, ea);                                                  \
+                         ldb, ldc, ldr, tiles_m, tiles_n, per, gm, ea);                                              \
   } while (0)
   if constexpr (!TA && !TB) {
     if (epi_kind == 3) { if (!fast) return SD_ERR_UNSUPPORTED; SD_GEMM_GO(3); SD_CHECK_LAUNCH(); return 0; }
@@ -620,7 +782,7 @@ int dispatch(const void* A, const void* B, void* C, const void* R, float* slabs,
   bool stag_ok = !g_no_fast_stage && (ta || tb || (K % BK) == 0) &&
                        ((long)K * (ta ? lda : 1) + (long)M * (ta ? 1 : lda)) * 2 < 0x70000000L &&
                        ((long)K * (tb ? ldb : 1) + (long)N * (tb ? 1 : ldb)) * 2 < 0x70000000L;
-  if (bm == 256 && nst == 9 && !stag_ok) nst = 3;
+  if (nst == 9 && (!stag_ok || (bm != 256 && bm != 64) || (bm == 64 && epi_kind >= 3))) nst = 3;
   SdProfScope prof(ta ? SD_K_GEMM_TN : (tb ? SD_K_GEMM_NN : ((bm == 256 && nst == 9) ? SD_K_GEMM_NT_STAG : SD_K_GEMM_NT)),
                    2.0 * M * N * K, st);
 #define SD_GO(BM_, NST_, TA_, TB_) \
@@ -630,6 +792,7 @@ int dispatch(const void* A, const void* B, void* C, const void* R, float* slabs,
     if (bm == 256 && nst == 9 && stag_ok) SD_GO(256, 9, TA_, TB_); \
     if (bm == 256 && nst == 2) SD_GO(256, 2, TA_, TB_);     \
     if (bm == 256) SD_GO(256, 3, TA_, TB_);                 \
+    if (bm == 64 && nst == 9) SD_GO(64, 9, TA_, TB_);       \
     if (bm == 64 && nst == 2) SD_GO(64, 2, TA_, TB_);       \
     if (bm == 64 && nst == 3) SD_GO(64, 3, TA_, TB_);       \
     if (bm == 64) SD_GO(64, 4, TA_, TB_);                   \
@@ -660,12 +823,16 @@ extern "C" void sd_gemm_force_variant(int bm, int nst) {
 }
 
 extern "C" int sd_gemm_splitk_plan(int M, int N, int K) {
-  // Measured (tests/bench_shapes.py --tune --cold): with prefetch that really overlaps, K <= 6144 is best unsplit;
-  // only the lm_head-class contraction (K = vocabulary) is split, onto 256x128 staggered tiles.
+  // The kernels are bound by the L2 -> LDS rate, i.e. by FLOP per staged byte, i.e. by tile area: a GEMM whose
+  // output has fewer than 256 tiles of 256x128 is split along K so that it can still use those tiles.  Measured
+  // (tests/bench_shapes.py --tune --cold, whole step): worth it from K = 6144 (4 slices: gate|up dX, +1 % step) and
+  // for the lm_head-class contraction (K = vocabulary, 8 slices); K <= 4096 is best unsplit on 64x128 tiles.
   const long tiles = (long)((M + 255) / 256) * ((N + BN - 1) / BN);
   const int kt = (K + BK - 1) / BK;
-  if (tiles >= 256 || kt < 256) return 1;
-  int s = (int)((512 + tiles - 1) / tiles);
+  static const int min_kt = getenv("SD_SPLITK_MIN_KT") ? atoi(getenv("SD_SPLITK_MIN_KT")) : 96;  // A/B measurements
+  if (tiles >= 256 || kt < min_kt) return 1;
+  static const int target = getenv("SD_SPLITK_TARGET") ? atoi(getenv("SD_SPLITK_TARGET")) : 256;
+  int s = (int)(((kt >= 256 ? 512 : target) + tiles - 1) / tiles);
   if (s > 8) s = 8;
   return s < 1 ? 1 : s;
 }

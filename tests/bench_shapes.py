@@ -37,7 +37,7 @@ def main():
     out = []
     g = torch.Generator(device=dev).manual_seed(0)
     lib = ops.load_lib()
-    variants = [(0, 0), (128, 2), (128, 3), (128, 4), (64, 2), (64, 3), (64, 4), (256, 9)] if "--tune" in sys.argv else [(0, 0)]
+    variants = [(0, 0), (128, 2), (128, 3), (128, 4), (64, 2), (64, 3), (64, 4), (256, 9), (64, 9)] if "--tune" in sys.argv else [(0, 0)]
     for name, m, n, k, ta, tb, sk in shapes:
         a = torch.randn((k, m) if ta else (m, k), device=dev, generator=g).bfloat16()
         b = torch.randn((k, n) if tb else (n, k), device=dev, generator=g).bfloat16()

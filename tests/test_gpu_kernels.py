@@ -73,7 +73,8 @@ def test_gemm_random(ops, M, N, K, ta, tb, res):
     check_close(f"gemm_{M}x{N}x{K}_ta{int(ta)}tb{int(tb)}r{int(res)}", got, ref, 6e-3, 3e-3)
 
 
-@pytest.mark.parametrize("bm,nst", [(256, 9), (256, 3), (256, 2), (128, 3), (64, 4), (64, 2), (128, 2 | 0x100), (64, 3 | 0x100)])
+@pytest.mark.parametrize("bm,nst", [(256, 9), (64, 9), (256, 3), (256, 2), (128, 3), (64, 4), (64, 2), (128, 2 | 0x100),
+                                    (64, 3 | 0x100)])
 @pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, True)])
 def test_gemm_forced_variants_exact(ops, bm, nst, ta, tb):
     """every tile height / ring depth the heuristic can pick, on integer data (must be exact), ragged edges."""
@@ -91,24 +92,28 @@ def test_gemm_forced_variants_exact(ops, bm, nst, ta, tb):
     assert torch.equal(got, _gemm_ref(a, b, ta, tb).float().bfloat16().float())
 
 
+@pytest.mark.parametrize("bm,K", [(256, 2112), (64, 2112), (64, 2048), (64, 64), (64, 192)])
 @pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, True)])
-def test_gemm_staggered_kernel_random(ops, ta, tb):
-    """the two-half staggered 256x128 kernel (forced), long K so the 3-stage ring wraps many times; run 3x (race screen)."""
+def test_gemm_staggered_kernel_random(ops, ta, tb, bm, K):
+    """the two-half staggered kernels (forced): 256x128 (halves split the rows) and 64x128 (halves split K; odd and
+    even numbers of K tiles, fewer tiles than ring stages), with a residual, long K so the 3-stage rings wrap many
+    times; run 3x (race screen)."""
     g = torch.Generator().manual_seed(77)
-    M, N, K = 1000, 520, 2112
+    M, N = 1000, 520
     a = bf(torch.randn((K, M) if ta else (M, K), generator=g))
     b = bf(torch.randn((K, N) if tb else (N, K), generator=g))
-    ref = _gemm_ref(a.float(), b.float(), ta, tb)
+    r = bf(torch.randn(M, N, generator=g) * 8)
+    ref = _gemm_ref(a.float(), b.float(), ta, tb, r.float())
     lib = ops.load_lib()
-    ad, bd = to_dev(a), to_dev(b)
+    ad, bd, rd = to_dev(a), to_dev(b), to_dev(r)
     outs = []
     for _ in range(3):
-        lib.sd_gemm_force_variant(256, 9)
+        lib.sd_gemm_force_variant(bm, 9)
         try:
-            outs.append(ops.gemm(ad, bd, ta, tb))
+            outs.append(ops.gemm(ad, bd, ta, tb, residual=rd))
         finally:
             lib.sd_gemm_force_variant(0, 0)
-    check_close(f"gemm_stag_ta{int(ta)}tb{int(tb)}", outs[0], ref, 6e-3, 3e-3)
+    check_close(f"gemm_stag{bm}_K{K}_ta{int(ta)}tb{int(tb)}", outs[0], ref, 6e-3, 3e-3)
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
 
 
