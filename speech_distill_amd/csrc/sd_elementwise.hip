@@ -229,43 +229,62 @@ __global__ __launch_bounds__(256) void qknorm_rope_bwd_kernel(const bf16* __rest
   const long i0 = (long)blockIdx.x * items_per_block;
   float accw[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // this lane's gain-gradient partial for q (hh<Hq) ...
   float acck[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // ... and for k
-  for (long base = i0 + (threadIdx.x >> 6) * 4; base < i0 + items_per_block; base += 16) {
-    const long idx = base + sub;
-    const bool ok = idx < total && idx < i0 + items_per_block;
-    const long id = idx < total ? idx : total - 1;
-    const int m = (int)(id / nh), hh = (int)(id % nh);
-    const int t = m % T;
-    float f[8], g[8], cs[8], sn[8], dy[8];
-    unpack8(*(const bf16x8*)(qkv + (long)m * (Hq + 2 * Hkv) * 128 + hh * 128 + j * 8), f);
-    unpack8(*(const bf16x8*)(dout + (long)m * nh * 128 + hh * 128 + j * 8), dy);
-    unpack8(*(const bf16x8*)((hh < Hq ? qw : kw) + j * 8), g);
-    unpack8(*(const bf16x8*)(cosb + (long)t * 128 + j * 8), cs);
-    unpack8(*(const bf16x8*)(sinb + (long)t * 128 + j * 8), sn);
-    float ss = 0.f;
+  const bf16x8 gq = *(const bf16x8*)(qw + j * 8), gk = *(const bf16x8*)(kw + j * 8);
+  // UN items per 16-lane group per trip, every load of the trip issued before the first use: the kernel is a chain of
+  // dependent HBM round trips otherwise (one item = 5 loads -> shuffles -> 1 store, 24 us for 38 MB at UN = 1)
+  constexpr int UN = 3;
+  for (long base = i0 + (threadIdx.x >> 6) * 4; base < i0 + items_per_block; base += 16 * UN) {
+    bf16x8 fv[UN], dyv[UN], csv[UN], snv[UN];
+    long ids[UN];
+    bool oks[UN];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) ss += f[e] * f[e];
-    ss += __shfl_xor(ss, 1, 64); ss += __shfl_xor(ss, 2, 64); ss += __shfl_xor(ss, 4, 64); ss += __shfl_xor(ss, 8, 64);
-    const float rs = rsqrtf(ss * (1.f / 128.f) + eps);
-    // RoPE^T:  dn[i] = dy[i] cos[i] + (i<64 ?  dy[i+64] sin[i+64] : -dy[i-64] sin[i-64])
-    float dn[8], dot = 0.f;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float z = dy[e] * sn[e];
-      const float pz = __shfl_xor(z, 8, 64);
-      dn[e] = dy[e] * cs[e] + ((j < 8) ? pz : -pz);
-      dot += dn[e] * g[e] * f[e] * rs;
+    for (int u = 0; u < UN; ++u) {
+      const long idx = base + 16 * u + sub;
+      oks[u] = idx < total && idx < i0 + items_per_block;
+      ids[u] = idx < total ? idx : total - 1;
+      const int m = (int)(ids[u] / nh), hh = (int)(ids[u] % nh);
+      const int t = m % T;
+      fv[u] = *(const bf16x8*)(qkv + (long)m * (Hq + 2 * Hkv) * 128 + hh * 128 + j * 8);
+      dyv[u] = *(const bf16x8*)(dout + (long)m * nh * 128 + hh * 128 + j * 8);
+      csv[u] = *(const bf16x8*)(cosb + (long)t * 128 + j * 8);
+      snv[u] = *(const bf16x8*)(sinb + (long)t * 128 + j * 8);
     }
-    dot += __shfl_xor(dot, 1, 64); dot += __shfl_xor(dot, 2, 64); dot += __shfl_xor(dot, 4, 64); dot += __shfl_xor(dot, 8, 64);
-    dot *= (1.f / 128.f);
-    float o[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float xh = f[e] * rs;
-      o[e] = rs * (dn[e] * g[e] - xh * dot);
-      const float gw = ok ? dn[e] * xh : 0.f;
-      if (hh < Hq) accw[e] += gw; else acck[e] += gw;
+    for (int u = 0; u < UN; ++u) {
+      const bool ok = oks[u];
+      const int m = (int)(ids[u] / nh), hh = (int)(ids[u] % nh);
+      float f[8], g[8], cs[8], sn[8], dy[8];
+      unpack8(fv[u], f);
+      unpack8(dyv[u], dy);
+      unpack8(hh < Hq ? gq : gk, g);
+      unpack8(csv[u], cs);
+      unpack8(snv[u], sn);
+      float ss = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) ss += f[e] * f[e];
+      ss += __shfl_xor(ss, 1, 64); ss += __shfl_xor(ss, 2, 64); ss += __shfl_xor(ss, 4, 64); ss += __shfl_xor(ss, 8, 64);
+      const float rs = rsqrtf(ss * (1.f / 128.f) + eps);
+      // RoPE^T:  dn[i] = dy[i] cos[i] + (i<64 ?  dy[i+64] sin[i+64] : -dy[i-64] sin[i-64])
+      float dn[8], dot = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float z = dy[e] * sn[e];
+        const float pz = __shfl_xor(z, 8, 64);
+        dn[e] = dy[e] * cs[e] + ((j < 8) ? pz : -pz);
+        dot += dn[e] * g[e] * f[e] * rs;
+      }
+      dot += __shfl_xor(dot, 1, 64); dot += __shfl_xor(dot, 2, 64); dot += __shfl_xor(dot, 4, 64); dot += __shfl_xor(dot, 8, 64);
+      dot *= (1.f / 128.f);
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float xh = f[e] * rs;
+        o[e] = rs * (dn[e] * g[e] - xh * dot);
+        const float gw = ok ? dn[e] * xh : 0.f;
+        if (hh < Hq) accw[e] += gw; else acck[e] += gw;
+      }
+      if (ok) *(bf16x8*)(dqkv + (long)m * (Hq + 2 * Hkv) * 128 + hh * 128 + j * 8) = pack8(o);
     }
-    if (ok) *(bf16x8*)(dqkv + (long)m * (Hq + 2 * Hkv) * 128 + hh * 128 + j * 8) = pack8(o);
   }
   const int slot = (threadIdx.x >> 6) * 4 + sub;
 #pragma unroll
@@ -386,7 +405,7 @@ extern "C" int sd_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd
 }
 
 extern "C" int64_t sd_rmsnorm_bwd_workspace_bytes(int M, int H) {
-  const int nb = (M + 7) / 8 < 256 ? (M + 7) / 8 : 256;
+  const int nb = (M + 3) / 4 < 512 ? (M + 3) / 4 : 512;
   return (int64_t)nb * H * 4;
 }
 
@@ -397,7 +416,7 @@ static int rmsnorm_bwd_any(const void* dy, const float* dy_slabs, int nsplit, co
                            int M, int H, void* reduce_stream, void* event, void* stream) {
   if (M <= 0 || (H & 7)) return SD_ERR_SHAPE;
   if (H > 4096) return SD_ERR_UNSUPPORTED;
-  int nb = (M + 7) / 8 < 256 ? (M + 7) / 8 : 256;
+  int nb = (M + 3) / 4 < 512 ? (M + 3) / 4 : 512;  // 2 workgroups (8 waves) per CU, one or two rows per wave
   const int rpb = (M + nb - 1) / nb;
   nb = (M + rpb - 1) / rpb;
   SdProfScope prof(SD_K_RMSNORM, ((dres ? 8.0 : 6.0) + (dy_slabs ? 4.0 * nsplit - 2.0 : 0.0)) * M * H, ST);
@@ -463,7 +482,7 @@ extern "C" int sd_qknorm_rope_fwd(const void* qkv, const void* q_gain, const voi
 
 static inline int qk_bwd_blocks(long items, int* ipb) {
   long per = (items + 511) / 512;
-  per = (per + 15) / 16 * 16;
+  per = (per + 47) / 48 * 48;  // a whole number of 16-lane-group trips of 3 items (qknorm_rope_bwd_kernel)
   *ipb = (int)per;
   return (int)((items + per - 1) / per);
 }

@@ -21,11 +21,15 @@ HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 def test_asm_transposed_reads_are_waited_before_use(src):
     tmp = tempfile.mkdtemp()
     out = os.path.join(tmp, "k.s")
-    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S",
-                    os.path.join(ROOT, "speech_distill_amd", "csrc", src), "-o", out], check=True)
-    pending, n_tr, hazards = {}, 0, []
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-amdgpu-mfma-vgpr-form=1",
+                    "--cuda-device-only", "-S", os.path.join(ROOT, "speech_distill_amd", "csrc", src), "-o", out],
+                   check=True)
+    assert "-amdgpu-mfma-vgpr-form=1" in open(os.path.join(ROOT, "speech_distill_amd", "csrc", "Makefile")).read()
+    pending, n_tr, hazards, n_acc, n_mfma = {}, 0, [], 0, 0
     for ln, line in enumerate(open(out)):
         t = line.strip()
+        n_acc += t.startswith("v_accvgpr")
+        n_mfma += t.startswith("v_mfma")
         if not t or t.startswith((";", ".")):
             continue
         if t.endswith(":"):
@@ -50,4 +54,7 @@ def test_asm_transposed_reads_are_waited_before_use(src):
             if regs & set(pending):
                 hazards.append((ln, t))
     assert n_tr > 100, "expected the asm transposed reads in the kernels"
+    # accumulators stay in VGPRs: no AGPR <-> VGPR copies around the VALU work (only the dK/dV kernel, whose two
+    # accumulator sets exceed 256 registers, keeps a few)
+    assert n_acc <= (0 if src == "sd_gemm.hip" else n_mfma * 2), (n_acc, n_mfma)
     assert not hazards, hazards[:5]
