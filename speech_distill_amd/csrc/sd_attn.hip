@@ -102,14 +102,20 @@ SD_DEV bf16x8 acc_frag(const f32x16& p, int s) {
 SD_DEV int acc_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
 
 // ------------------------------------------------------------------------------------------ forward
-// grid (ceil(T/128), Hq, B), 256 threads: wave w owns query rows q0 + 32w .. +31.
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ Kp,
+// grid (ceil(T/128), Hq, B), 512 threads.  Waves w and w+4 own the SAME 32 query rows q0 + 32(w&3) .. +31 and split
+// the K/V tiles between them (half = w>>2 takes tiles t = 2i + half): at B*T = 2048 tokens there are only 1 024
+// row-blocks of 32 queries, one wave per SIMD, and a single wave runs its DMA issue, LDS reads, MFMAs and softmax
+// VALU strictly one after the other (~5 000 cycles per K/V tile for 1 024 cycles of MFMA); with two independent
+// waves per SIMD they overlap.  Each half streams its own tiles through its own double buffer (2 x (K,V) = 64 KiB);
+// the two partial (m, l, O) states are merged through LDS at the end (fixed order: deterministic).
+__global__ __launch_bounds__(512) void attn_fwd_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ Kp,
                                                        const bf16* __restrict__ Vp, bf16* __restrict__ O,
                                                        float* __restrict__ LSE, const int* __restrict__ kv_len, long ldq,
                                                        long ldk, long ldv, long ldo, int T, int Hq, int Hkv,
                                                        float scale) {
-  __shared__ __attribute__((aligned(16))) char smem[6 * TILE];  // 3 stages x (K,V)
-  const int lane = lane_id(), w = wave_id_uniform();
+  __shared__ __attribute__((aligned(16))) char smem[8 * TILE];  // 2 halves x 2 stages x (K,V)
+  const int lane = lane_id(), w8 = wave_id_uniform();
+  const int half = w8 >> 2, w = w8 & 3;
   const int qt = gridDim.x - 1 - blockIdx.x;  // heaviest (latest) query tiles first
   const int hq = blockIdx.y, b = blockIdx.z;
   const int hkv = hq / (Hq / Hkv);
@@ -138,32 +144,30 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
 
   const int kv_hi = min(q0 + 128, T);
   const int nkv = (kv_hi + 63) / 64;
+  const int nit = (nkv + 1) >> 1;  // trips of both halves; half 1 idles through the last one when nkv is odd
   TileDma kd, vd;
   kd.init(kb, ldk, T, w, lane);
   vd.init(vb, ldv, T, w, lane);
-  // 3-stage K/V ring: tile t+2 is issued while tile t is used; the wait for tile t is a counted vmcnt that
-  // leaves tile t+1 in flight across the raw barrier.  Tiles past the end are still issued (rows beyond the
-  // slice read as zeros), which keeps the count uniform.
-  kd.issue(0, smem, w);
-  vd.issue(0, smem + TILE, w);
-  kd.issue(64, smem + 2 * TILE, w);
-  vd.issue(64, smem + 3 * TILE, w);
-  int cur_i = 0, nxt_i = 2;
-  for (int t = 0; t < nkv; ++t) {
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+  char* ring = smem + half * 4 * TILE;
+  // double buffer per half: tile i+1 is issued while tile i is used.  Tiles past the end are still issued (rows beyond
+  // the slice read as zeros) and never used.
+  kd.issue(half * 64, ring, w);
+  vd.issue(half * 64, ring + TILE, w);
+  int cur_i = 0;
+  for (int i = 0; i < nit; ++i) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // my half's tile i has landed; everybody is done reading the other stage
     asm volatile("" ::: "memory");
     {
-      char* nx = smem + nxt_i * 2 * TILE;
-      kd.issue((t + 2) * 64, nx, w);
-      vd.issue((t + 2) * 64, nx + TILE, w);
+      char* nx = ring + (cur_i ^ 1) * 2 * TILE;
+      kd.issue((2 * (i + 1) + half) * 64, nx, w);
+      vd.issue((2 * (i + 1) + half) * 64, nx + TILE, w);
     }
-    const char* ks = smem + cur_i * 2 * TILE;
+    const char* ks = ring + cur_i * 2 * TILE;
     const char* vs = ks + TILE;
-    cur_i = (cur_i == 2) ? 0 : cur_i + 1;
-    nxt_i = (nxt_i == 2) ? 0 : nxt_i + 1;
-    const int kv0 = t * 64;
-    if (kv0 <= q0w + 31) {  // wave-uniform: some key of this tile is visible to some row of this wave
+    cur_i ^= 1;
+    const int kv0 = (2 * i + half) * 64;
+    if (kv0 < kv_hi && kv0 <= q0w + 31) {  // wave-uniform: some key of this tile is visible to some row of this wave
       const bool need_mask = (kv0 + 63 > q0w) || (kv0 + 63 >= klen);  // wave-uniform: tile touches the diagonal / padding
       f32x16 s[2];
 #pragma unroll
@@ -220,7 +224,31 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
         }
     }
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the tail tiles before the workgroup retires
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the tail tiles before the ring is reused
+  __syncthreads();
+  // merge the two halves: half 1 parks (m, l, O) in LDS, half 0 combines.  Layout [w][slot][lane] floats.
+  float* xo = (float*)smem + (long)w * 66 * 64;
+  if (half == 1) {
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) xo[(db * 16 + e) * 64 + lane] = o[db][e];
+    xo[64 * 64 + lane] = m;
+    xo[65 * 64 + lane] = l;
+  }
+  __syncthreads();
+  if (half == 1) return;
+  {
+    const float m1 = xo[64 * 64 + lane], l1 = xo[65 * 64 + lane];
+    const float mn = fmaxf(m, m1);
+    const float a0 = __builtin_amdgcn_exp2f((m - mn) * c), a1 = __builtin_amdgcn_exp2f((m1 - mn) * c);
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) o[db][e] = o[db][e] * a0 + xo[(db * 16 + e) * 64 + lane] * a1;
+    l = l * a0 + l1 * a1;
+    m = mn;
+  }
   l += __shfl_xor(l, 32, 64);
   const float inv = 1.f / l;
   if (q < T) {
@@ -527,7 +555,7 @@ extern "C" int sd_attn_fwd(const void* q, const void* k, const void* v, void* o,
   if (int e = check_common(B, T, Hq, Hkv, ldq, ldk, ldv, ldo)) return e;
   if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) & 15) return SD_ERR_ALIGN;
   SdProfScope prof(SD_K_ATTN_FWD, 2.0 * B * Hq * (double)T * T * D, (hipStream_t)stream);  // 2 products, causal half
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3((T + 127) / 128, Hq, B), dim3(256), 0, (hipStream_t)stream, (const bf16*)q,
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3((T + 127) / 128, Hq, B), dim3(512), 0, (hipStream_t)stream, (const bf16*)q,
                      (const bf16*)k, (const bf16*)v, (bf16*)o, lse, kv_len, ldq, ldk, ldv, ldo, T, Hq, Hkv, scale);
   SD_CHECK_LAUNCH();
   return 0;
