@@ -520,6 +520,177 @@ __global__ __launch_bounds__(512, 2) void gemm_stag_kernel(const bf16* __restric
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Persistent form of the staggered 256x128x64 kernel for launches with more tiles than CUs (lm_head forward and dW,
+// the teacher's gate|up: 3-20 tiles per CU).  Measured on the one-tile-per-workgroup kernel: a K-step takes 0.79 us
+// (1.36 PFLOP/s chip-wide) but every tile costs another ~8 us -- descriptor set-up and the first two stage loads in
+// front, LDS-staged write-out, workgroup retire and the launch of the next one behind -- 38 % of a K = 1024 tile.
+// Here a workgroup walks its tiles (the same per-XCD order as the other kernels) as ONE K stream: the LDS-DMA runs
+// two K-steps ahead ACROSS tile boundaries (the tile origin is folded into the scalar offset of the buffer load),
+// and a wave that finishes a tile stores its 64x64 block straight from the accumulators (8-byte pieces, merged in L2)
+// -- LDS stays with the ring, nothing waits for the next tile's operands.
+//   EPI 0: C = A.B          EPI 3: SwiGLU (B tile = 64 gate rows | 64 up rows; each wave reads 32 + 32 of them, so gate
+//   and up of the same outputs sit in the same lane: act = silu(gate) * up in registers, out2 [M, I]).
+template <bool TA, bool TB, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_pstag_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B, bf16* C,
+                                                            int M, int N, int K, long lda, long ldb, long ldc, int tiles_m,
+                                                            int tiles_n, int group_m, EpiArgs ea) {
+  constexpr int BM = 256, NW = 8, NST = 3;
+  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;  // 48 KiB
+  constexpr int LOADS = (BM + BN) / (8 * NW);                                             // 6 per wave per tile
+  __shared__ __attribute__((aligned(16))) char smem[NST * STAGE];                         // 144 KiB
+  const int lane = lane_id();
+  const int w = wave_id_uniform();
+  const int wm = w >> 1, wn = w & 1;
+  const int half = w >> 2;
+  const int ntiles = tiles_m * tiles_n;
+  const int nk = (K + BK - 1) / BK;
+  // my tiles: xcd_remap(blockIdx.x + k * gridDim.x) (gridDim.x is a multiple of 8, or ntiles itself)
+  const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int total = my_tiles * nk;  // K-steps of this workgroup
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  FastStage<TA, BM, NW> fa;
+  FastStage<TB, BN, NW> fb;
+  fa.init(A, lda, 0, (unsigned)((TA ? ((long)(K - 1) * lda + M) : ((long)(M - 1) * lda + K)) * 2), w, lane);
+  fb.init(B, ldb, 0, (unsigned)((TB ? ((long)(K - 1) * ldb + N) : ((long)(N - 1) * ldb + K)) * 2), w, lane,
+          EPI == 3 ? ea.I - 64 : 0);
+  // prefetch cursor (runs two K-steps ahead of the compute cursor, across tiles)
+  int pf_tile = 0, pf_k = 0;
+  unsigned pf_a = 0, pf_b = 0;  // byte offsets of the prefetch tile's origin in A and B
+  auto origin = [&](int idx, int& tm, int& tn) {
+    const int t = xcd_remap((int)blockIdx.x + idx * (int)gridDim.x, ntiles);
+    tile_coords(t, tiles_m, tiles_n, group_m, tm, tn);
+  };
+  auto pf_set = [&](int idx) {
+    int tm = 0, tn = 0;
+    if (idx < my_tiles) origin(idx, tm, tn);
+    const long m0 = (long)tm * BM, nb0 = (EPI == 3) ? (long)tn * 64 : (long)tn * BN;
+    pf_a = (unsigned)((TA ? m0 : m0 * lda) * 2);
+    pf_b = (unsigned)((TB ? nb0 : nb0 * ldb) * 2);
+  };
+  auto pf_issue = [&](char* stage) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int sa = (int)(pf_a + (unsigned)(pf_k * BK) * (unsigned)fa.kstep);
+    const int sb = (int)(pf_b + (unsigned)(pf_k * BK) * (unsigned)fb.kstep);
+#pragma unroll
+    for (int i = 0; i < FastStage<TA, BM, NW>::NI; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(fa.rsrc, (SD_LDS void*)(stage + (w * FastStage<TA, BM, NW>::NI + i) * 1024),
+                                               16, fa.voff[i], sa, 0, 0);
+#pragma unroll
+    for (int i = 0; i < FastStage<TB, BN, NW>::NI; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(
+          fb.rsrc, (SD_LDS void*)(stage + A_BYTES + (w * FastStage<TB, BN, NW>::NI + i) * 1024), 16, fb.voff[i], sb, 0, 0);
+#endif
+    if (++pf_k == nk) { pf_k = 0; pf_set(++pf_tile); }
+  };
+  (void)pf_a; (void)pf_b;
+  pf_set(0);
+  pf_issue(smem);
+  pf_issue(smem + STAGE);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  if (half == 1) __builtin_amdgcn_s_barrier();  // second half runs one phase behind
+
+  int cur_i = 0, nxt_i = 2, ck = 0, ctile = 0;
+  for (int g = 0; g < total; ++g) {
+    // ---- LOAD(g): K-step g+2 of the stream (steps past the end re-read the last origin and are never used)
+    pf_issue(smem + nxt_i * STAGE);
+    const char* cur = smem + cur_i * STAGE;
+    bf16x8 af[2][4], bfr[2][4];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      if constexpr (TA) {
+        load_frags_tr<BM, 4>(cur, wm * 64, kk, lane, af[kk]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[kk][i] = load_frag<TA, BM>(cur, wm * 64 + i * 16, kk, lane);
+      }
+      if constexpr (EPI == 3) {
+        static_assert(EPI != 3 || !TB, "SwiGLU epilogue: forward (NT) only");
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          bfr[kk][j] = load_frag<false, BN>(cur + A_BYTES, (j >> 1) * 64 + wn * 32 + (j & 1) * 16, kk, lane);
+      } else if constexpr (TB) {
+        load_frags_tr<BN, 4>(cur + A_BYTES, wn * 64, kk, lane, bfr[kk]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bfr[kk][j] = load_frag<TB, BN>(cur + A_BYTES, wn * 64 + j * 16, kk, lane);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- COMPUTE(g)
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(bfr[kk][j], af[kk][i], acc[i][j]);
+    __builtin_amdgcn_s_setprio(0);
+    if (++ck == nk) {  // tile finished: store this wave's 64x64 block from registers, clear, go on with the next tile
+      ck = 0;
+      int tm, tn;
+      origin(ctile++, tm, tn);
+      const int m0 = tm * BM;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int gm = m0 + wm * 64 + i * 16 + (lane & 15);
+        if constexpr (EPI == 3) {
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int gc = tn * 64 + wn * 32 + j * 16 + (lane >> 4) * 4;  // column of act; gate at gc, up at I + gc
+            bf16x4 a4, g4, u4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              // same rounding as the unfused pair: gate|up are rounded to bf16 first (sd_swiglu_fwd reads them back)
+              const bf16 gb = (bf16)acc[i][j][e], ub = (bf16)acc[i][j + 2][e];
+              const float gf = (float)gb, uf = (float)ub;
+              g4[e] = gb; u4[e] = ub;
+              a4[e] = (bf16)(gf / (1.f + __expf(-gf)) * uf);
+            }
+            if (gm < M && gc < ea.I) {
+              *(bf16x4*)(ea.out2 + (long)gm * ea.ld2 + gc) = a4;
+              if (C) {
+                *(bf16x4*)(C + (long)gm * ldc + gc) = g4;
+                *(bf16x4*)(C + (long)gm * ldc + ea.I + gc) = u4;
+              }
+            }
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int gn = tn * BN + wn * 64 + j * 16 + (lane >> 4) * 4;
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (bf16)acc[i][j][e];
+            if (gm < M && gn < N) *(bf16x4*)(C + (long)gm * ldc + gn) = o;
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    cur_i = (cur_i == 2) ? 0 : cur_i + 1;
+    nxt_i = (nxt_i == 2) ? 0 : nxt_i + 1;
+  }
+  if (half == 0) __builtin_amdgcn_s_barrier();  // re-align the halves
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the tail prefetches before the workgroup retires
+}
+
+// ---------------------------------------------------------------------------------------------------
 // K-split staggered 64x128x64 kernel (8 waves) for GEMMs with few output tiles and a long K (N = hidden: o / down
 // forward, every dX; 128-256 tiles of 64x128 on 256 CUs).  With one 4-wave workgroup per CU there is one wave per
 // SIMD and its DMA issue, LDS reads and MFMAs run back to back (~1 270 cycles per K-step for 256 cycles of MFMA).
@@ -698,12 +869,27 @@ int launch(const void* A, const void* B, void* C, const void* R, float* slabs, i
   const long bytes_b = (TB ? ((long)(K - 1) * ldb + N) : ((long)(N - 1) * ldb + K)) * 2;
   const long span = ((long)kt_all + 6) * BK * 2 * (TA ? lda : 1) + bytes_a;
   const long span_b = ((long)kt_all + 6) * BK * 2 * (TB ? ldb : 1) + bytes_b;
+  // persistent kernel: one workgroup per CU (a multiple of 8 so that every workgroup stays on its XCD's tile run)
+  static const int persist_grid = [] {
+    if (getenv("SD_GEMM_NO_PERSIST")) return 0;  // A/B measurements
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+      return 0;
+    return cus & ~7;
+  }();
   static const int gm_env = getenv("SD_GEMM_GROUP_M") ? atoi(getenv("SD_GEMM_GROUP_M")) : 0;  // A/B measurements
   int gm = gm_env > 0 ? gm_env : (BM == 256 ? 4 : 8);
   if (gm > tiles_m) gm = tiles_m;
   const bool fast = !g_no_fast_stage && (TA || TB || (K % BK) == 0) && span < 0x7fffffffL && span_b < 0x7fffffffL;
 #define SD_GEMM_GO(EPI)                                                                                              \
   do {                                                                                                               \
+    if constexpr (BM == 256 && NST == 9 && (EPI == 0 || EPI == 3)) {                                                 \
+      if (splits == 1 && tiles_m * tiles_n > persist_grid && persist_grid > 0) {                                       \
+        hipLaunchKernelGGL((gemm_pstag_kernel<TA, TB, EPI>), dim3(persist_grid), block, 0, st, (const bf16*)A,         \
+                           (const bf16*)B, (bf16*)C, M, N, K, lda, ldb, ldc, tiles_m, tiles_n, gm, ea);                \
+        break;                                                                                                         \
+      }                                                                                                                \
+    }                                                                                                                  \
     if constexpr (BM == 256 && NST == 9) {                                                                           \
       hipLaunchKernelGGL((gemm_stag_kernel<TA, TB, EPI>), grid, block, 0, st, (const bf16*)A, (const bf16*)B,          \
                          (bf16*)C, (const bf16*)R, slabs, M, N, K, lda, ldb, ldc, ldr, tiles_m, tiles_n, per, gm, ea); \

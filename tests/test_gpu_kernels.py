@@ -146,6 +146,54 @@ def test_gemm_fused_epilogues_equal_the_separate_kernels(ops, bm, nst):
     assert torch.equal(act, act_ref) and torch.equal(act2, act_ref), float((act.float() - act_ref.float()).abs().max())
 
 
+@pytest.mark.parametrize("K", [64, 128, 192, 1088])
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, True)])
+def test_gemm_persistent_kernel(ops, ta, tb, K):
+    """more 256x128 tiles than CUs -> the persistent staggered kernel: one K stream across tile boundaries (K of 1, 2,
+    3 and 17 steps per tile), ragged M and N edges, register epilogue; must equal the one-tile-per-workgroup kernel
+    bit for bit (same accumulation order); run twice (race screen)."""
+    g = torch.Generator().manual_seed(K)
+    M, N = 1000, 128 * 83 + 40
+    a = bf(torch.randn((K, M) if ta else (M, K), generator=g))
+    b = bf(torch.randn((K, N) if tb else (N, K), generator=g))
+    ad, bd = to_dev(a), to_dev(b)
+    lib = ops.load_lib()
+    outs = []
+    for _ in range(2):
+        lib.sd_gemm_force_variant(256, 9)
+        try:
+            outs.append(ops.gemm(ad, bd, ta, tb))
+        finally:
+            lib.sd_gemm_force_variant(0, 0)
+    lib.sd_gemm_force_variant(128, 3)
+    try:
+        other = ops.gemm(ad, bd, ta, tb)
+    finally:
+        lib.sd_gemm_force_variant(0, 0)
+    check_close(f"gemm_persist_K{K}_ta{int(ta)}tb{int(tb)}", outs[0], _gemm_ref(a.float(), b.float(), ta, tb), 6e-3, 3e-3)
+    assert torch.equal(outs[0], outs[1])
+    assert torch.equal(outs[0], other)
+
+
+def test_gemm_persistent_swiglu(ops):
+    """gate|up GEMM + SwiGLU on the persistent kernel (I/64 * M/256 > number of CUs): bit-identical to GEMM + swiglu."""
+    g = torch.Generator().manual_seed(5)
+    M, K, I = 1100, 192, 64 * 90
+    x = to_dev(bf(torch.randn(M, K, generator=g)))
+    wgu = to_dev(bf(torch.randn(2 * I, K, generator=g) * 0.1))
+    lib = ops.load_lib()
+    lib.sd_gemm_force_variant(128, 3)
+    try:
+        gu_ref = ops.gemm(x, wgu)
+    finally:
+        lib.sd_gemm_force_variant(0, 0)
+    act_ref = ops.swiglu_fwd(gu_ref)
+    act, gu = ops.gemm_swiglu(x, wgu)
+    act2, none = ops.gemm_swiglu(x, wgu, save_gu=False)
+    assert torch.equal(gu, gu_ref) and none is None
+    assert torch.equal(act, act_ref) and torch.equal(act2, act_ref)
+
+
 def test_gemm_split_k(ops):
     """few tiles + long K -> fp32 slabs + fixed-order reduce (the lm_head dX shape class)."""
     g = torch.Generator().manual_seed(6)
