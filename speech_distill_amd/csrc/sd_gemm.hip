@@ -527,80 +527,124 @@ __global__ __launch_bounds__(512, 2) void gemm_stag_kernel(const bf16* __restric
 // Here a workgroup walks its tiles (the same per-XCD order as the other kernels) as ONE K stream: the LDS-DMA runs
 // two K-steps ahead ACROSS tile boundaries (the tile origin is folded into the scalar offset of the buffer load),
 // and a wave that finishes a tile stores its 64x64 block straight from the accumulators (8-byte pieces, merged in L2)
-// -- LDS stays with the ring, nothing waits for the next tile's operands.
+// -- LDS stays with the ring, nothing waits for the next tile's operands.  12 waves: 8 compute (the two staggered
+// halves of gemm_stag_kernel) + 4 producers that issue every LDS-DMA and do all the waiting on memory.
 //   EPI 0: C = A.B          EPI 3: SwiGLU (B tile = 64 gate rows | 64 up rows; each wave reads 32 + 32 of them, so gate
 //   and up of the same outputs sit in the same lane: act = silu(gate) * up in registers, out2 [M, I]).
 template <bool TA, bool TB, int EPI>
-__global__ __launch_bounds__(512, 2) void gemm_pstag_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B, bf16* C,
-                                                            int M, int N, int K, long lda, long ldb, long ldc, int tiles_m,
-                                                            int tiles_n, int group_m, EpiArgs ea) {
-  constexpr int BM = 256, NW = 8, NST = 3;
+__global__ __launch_bounds__(768) void gemm_pstag_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B, bf16* C,
+                                                         int M, int N, int K, long lda, long ldb, long ldc, int tiles_m,
+                                                         int tiles_n, int group_m, EpiArgs ea) {
+  constexpr int BM = 256, NW = 8, NPROD = 4, NST = 3;
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;  // 48 KiB
-  constexpr int LOADS = (BM + BN) / (8 * NW);                                             // 6 per wave per tile
-  __shared__ __attribute__((aligned(16))) char smem[NST * STAGE];                         // 144 KiB
+  constexpr int LOADS = (BM + BN) / (8 * NPROD);                                          // 12 per producer wave per tile
+  __shared__ __attribute__((aligned(16))) char smem[NST * STAGE + 8 * 2048];              // 144 KiB ring + 16 KiB store patches
   const int lane = lane_id();
   const int w = wave_id_uniform();
-  const int wm = w >> 1, wn = w & 1;
-  const int half = w >> 2;
   const int ntiles = tiles_m * tiles_n;
   const int nk = (K + BK - 1) / BK;
   // my tiles: xcd_remap(blockIdx.x + k * gridDim.x) (gridDim.x is a multiple of 8, or ntiles itself)
   const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
   const int total = my_tiles * nk;  // K-steps of this workgroup
+  auto origin = [&](int idx, int& tm, int& tn) {
+    const int t = xcd_remap((int)blockIdx.x + idx * (int)gridDim.x, ntiles);
+    tile_coords(t, tiles_m, tiles_n, group_m, tm, tn);
+  };
 
+  // ------------------------------------------------------------------ producer waves 8..11: the operand stream
+  // They alone issue LDS-DMA and wait on vmcnt, so the 8 compute waves never wait for memory: gfx950 counts loads
+  // and stores in ONE in-order counter, and a compute wave that had just stored its finished tile would sit at its
+  // next counted wait until those stores were acknowledged (~5 us per tile measured).  Barrier count per wave:
+  // 1 + 2 per K-step + 1, the same in all three roles.
+  if (w >= NW) {
+    const int pw = w - NW;
+    FastStage<TA, BM, NPROD> fa;
+    FastStage<TB, BN, NPROD> fb;
+    fa.init(A, lda, 0, (unsigned)((TA ? ((long)(K - 1) * lda + M) : ((long)(M - 1) * lda + K)) * 2), pw, lane);
+    fb.init(B, ldb, 0, (unsigned)((TB ? ((long)(K - 1) * ldb + N) : ((long)(N - 1) * ldb + K)) * 2), pw, lane,
+            EPI == 3 ? ea.I - 64 : 0);
+    int pf_tile = 0, pf_k = 0;
+    unsigned pf_a = 0, pf_b = 0;  // byte offsets of the prefetch tile's origin in A and B
+    (void)pf_a; (void)pf_b;
+    auto pf_set = [&](int idx) {
+      int tm = 0, tn = 0;
+      if (idx < my_tiles) origin(idx, tm, tn);
+      const long m0 = (long)tm * BM, nb0 = (EPI == 3) ? (long)tn * 64 : (long)tn * BN;
+      pf_a = (unsigned)((TA ? m0 : m0 * lda) * 2);
+      pf_b = (unsigned)((TB ? nb0 : nb0 * ldb) * 2);
+    };
+    auto pf_issue = [&](char* stage) {
+#if defined(__HIP_DEVICE_COMPILE__)
+      const int sa = (int)(pf_a + (unsigned)(pf_k * BK) * (unsigned)fa.kstep);
+      const int sb = (int)(pf_b + (unsigned)(pf_k * BK) * (unsigned)fb.kstep);
+#pragma unroll
+      for (int i = 0; i < FastStage<TA, BM, NPROD>::NI; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+            fa.rsrc, (SD_LDS void*)(stage + (pw * FastStage<TA, BM, NPROD>::NI + i) * 1024), 16, fa.voff[i], sa, 0, 0);
+#pragma unroll
+      for (int i = 0; i < FastStage<TB, BN, NPROD>::NI; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+            fb.rsrc, (SD_LDS void*)(stage + A_BYTES + (pw * FastStage<TB, BN, NPROD>::NI + i) * 1024), 16, fb.voff[i], sb,
+            0, 0);
+#endif
+      if (++pf_k == nk) { pf_k = 0; pf_set(++pf_tile); }
+    };
+    pf_set(0);
+    pf_issue(smem);
+    pf_issue(smem + STAGE);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    int nxt = 2;
+    for (int g = 0; g < total; ++g) {
+      // phase 2g: K-step g+2 of the stream (steps past the end re-read the first origin and are never used) into the
+      // stage whose last readers (K-step g-1) finished before the barrier just passed; then K-step g+1 has landed
+      pf_issue(smem + nxt * STAGE);
+      nxt = (nxt == 2) ? 0 : nxt + 1;
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_s_barrier();  // phase 2g+1: nothing to do
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the tail prefetches before the workgroup retires
+    return;
+  }
+
+  // ------------------------------------------------------------------ compute waves 0..7
+  const int wm = w >> 1, wn = w & 1;
+  const int half = w >> 2;
   f32x4 acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  FastStage<TA, BM, NW> fa;
-  FastStage<TB, BN, NW> fb;
-  fa.init(A, lda, 0, (unsigned)((TA ? ((long)(K - 1) * lda + M) : ((long)(M - 1) * lda + K)) * 2), w, lane);
-  fb.init(B, ldb, 0, (unsigned)((TB ? ((long)(K - 1) * ldb + N) : ((long)(N - 1) * ldb + K)) * 2), w, lane,
-          EPI == 3 ? ea.I - 64 : 0);
-  // prefetch cursor (runs two K-steps ahead of the compute cursor, across tiles)
-  int pf_tile = 0, pf_k = 0;
-  unsigned pf_a = 0, pf_b = 0;  // byte offsets of the prefetch tile's origin in A and B
-  auto origin = [&](int idx, int& tm, int& tn) {
-    const int t = xcd_remap((int)blockIdx.x + idx * (int)gridDim.x, ntiles);
-    tile_coords(t, tiles_m, tiles_n, group_m, tm, tn);
-  };
-  auto pf_set = [&](int idx) {
-    int tm = 0, tn = 0;
-    if (idx < my_tiles) origin(idx, tm, tn);
-    const long m0 = (long)tm * BM, nb0 = (EPI == 3) ? (long)tn * 64 : (long)tn * BN;
-    pf_a = (unsigned)((TA ? m0 : m0 * lda) * 2);
-    pf_b = (unsigned)((TB ? nb0 : nb0 * ldb) * 2);
-  };
-  auto pf_issue = [&](char* stage) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    const int sa = (int)(pf_a + (unsigned)(pf_k * BK) * (unsigned)fa.kstep);
-    const int sb = (int)(pf_b + (unsigned)(pf_k * BK) * (unsigned)fb.kstep);
-#pragma unroll
-    for (int i = 0; i < FastStage<TA, BM, NW>::NI; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(fa.rsrc, (SD_LDS void*)(stage + (w * FastStage<TA, BM, NW>::NI + i) * 1024),
-                                               16, fa.voff[i], sa, 0, 0);
-#pragma unroll
-    for (int i = 0; i < FastStage<TB, BN, NW>::NI; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(
-          fb.rsrc, (SD_LDS void*)(stage + A_BYTES + (w * FastStage<TB, BN, NW>::NI + i) * 1024), 16, fb.voff[i], sb, 0, 0);
-#endif
-    if (++pf_k == nk) { pf_k = 0; pf_set(++pf_tile); }
-  };
-  (void)pf_a; (void)pf_b;
-  pf_set(0);
-  pf_issue(smem);
-  pf_issue(smem + STAGE);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_barrier();                 // the first two K-steps have landed
   if (half == 1) __builtin_amdgcn_s_barrier();  // second half runs one phase behind
 
-  int cur_i = 0, nxt_i = 2, ck = 0, ctile = 0;
+  int cur_i = 0, ck = 0, ctile = 0;
+  // EPI 0: the finished 64x64 block of this wave, rounded to bf16, leaves in 8 pieces of 8 rows x 128 B.  A piece goes
+  // through 2 KiB of LDS of the wave's own (XOR-swizzled 16-byte chunks) so that a store instruction writes whole
+  // 128-byte lines instead of 16 x 4 pieces of 32 B (-1.1 us per tile).  Spreading the pieces over the K-steps of the
+  // next tile (all CUs reach their tile boundary together) was measured and bought nothing.
+  bf16x4 pend[16];
+  int pend_m0 = 0, pend_n0 = 0;
+  char* ep = smem + NST * STAGE + w * 2048;
+  auto store_piece = [&](int q) {  // q = 2 i + hh (compile-time after unrolling)
+    const int i = q >> 1, hh = q & 1;
+    if (hh == 0) {
+      const int r = lane & 15, q4 = lane >> 4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        *(bf16x4*)(ep + r * 128 + (((2 * j + (q4 >> 1)) ^ (r & 7)) << 4) + (q4 & 1) * 8) = pend[i * 4 + j];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    const int rr = hh * 8 + (lane >> 3), cc = lane & 7;
+    const bf16x8 v = *(const bf16x8*)(ep + rr * 128 + ((cc ^ (rr & 7)) << 4));
+    const int gmr = pend_m0 + i * 16 + rr, gn = pend_n0 + cc * 8;
+    if (gmr < M && gn < N) *(bf16x8*)(C + (long)gmr * ldc + gn) = v;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the patch may be overwritten by the next piece
+  };
   for (int g = 0; g < total; ++g) {
-    // ---- LOAD(g): K-step g+2 of the stream (steps past the end re-read the last origin and are never used)
-    pf_issue(smem + nxt_i * STAGE);
+    // ---- LOAD(g): fragments of K-step g
     const char* cur = smem + cur_i * STAGE;
     bf16x8 af[2][4], bfr[2][4];
 #pragma unroll
@@ -623,7 +667,6 @@ __global__ __launch_bounds__(512, 2) void gemm_pstag_kernel(const bf16* __restri
         for (int j = 0; j < 4; ++j) bfr[kk][j] = load_frag<TB, BN>(cur + A_BYTES, wn * 64 + j * 16, kk, lane);
       }
     }
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
@@ -637,7 +680,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pstag_kernel(const bf16* __restri
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(bfr[kk][j], af[kk][i], acc[i][j]);
     __builtin_amdgcn_s_setprio(0);
-    if (++ck == nk) {  // tile finished: store this wave's 64x64 block from registers, clear, go on with the next tile
+    if (++ck == nk) {  // tile finished: park / store this wave's 64x64 block, clear, go on with the next tile
       ck = 0;
       int tm, tn;
       origin(ctile++, tm, tn);
@@ -667,27 +710,31 @@ __global__ __launch_bounds__(512, 2) void gemm_pstag_kernel(const bf16* __restri
             }
           }
         } else {
+          // park the block as bf16; it is stored a little per K-step during the next tile (store_piece below)
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            const int gn = tn * BN + wn * 64 + j * 16 + (lane >> 4) * 4;
             bf16x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = (bf16)acc[i][j][e];
-            if (gm < M && gn < N) *(bf16x4*)(C + (long)gm * ldc + gn) = o;
+            pend[i * 4 + j] = o;
           }
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      if constexpr (EPI == 0) {
+        pend_m0 = m0 + wm * 64;
+        pend_n0 = tn * BN + wn * 64;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) store_piece(q);
       }
     }
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     cur_i = (cur_i == 2) ? 0 : cur_i + 1;
-    nxt_i = (nxt_i == 2) ? 0 : nxt_i + 1;
   }
   if (half == 0) __builtin_amdgcn_s_barrier();  // re-align the halves
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the tail prefetches before the workgroup retires
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -885,7 +932,7 @@ int launch(const void* A, const void* B, void* C, const void* R, float* slabs, i
   do {                                                                                                               \
     if constexpr (BM == 256 && NST == 9 && (EPI == 0 || EPI == 3)) {                                                 \
       if (splits == 1 && tiles_m * tiles_n > persist_grid && persist_grid > 0) {                                       \
-        hipLaunchKernelGGL((gemm_pstag_kernel<TA, TB, EPI>), dim3(persist_grid), block, 0, st, (const bf16*)A,         \
+        hipLaunchKernelGGL((gemm_pstag_kernel<TA, TB, EPI>), dim3(persist_grid), dim3(768), 0, st, (const bf16*)A,     \
                            (const bf16*)B, (bf16*)C, M, N, K, lda, ldb, ldc, tiles_m, tiles_n, gm, ea);                \
         break;                                                                                                         \
       }                                                                                                                \
