@@ -531,14 +531,19 @@ __global__ __launch_bounds__(512, 2) void gemm_stag_kernel(const bf16* __restric
 // halves of gemm_stag_kernel) + 4 producers that issue every LDS-DMA and do all the waiting on memory.
 //   EPI 0: C = A.B          EPI 3: SwiGLU (B tile = 64 gate rows | 64 up rows; each wave reads 32 + 32 of them, so gate
 //   and up of the same outputs sit in the same lane: act = silu(gate) * up in registers, out2 [M, I]).
-template <bool TA, bool TB, int EPI>
+// (A 128 x 128 form of this kernel with a 4-stage ring was measured on the N = hidden shapes: no faster than the
+// 4-wave gemm_bf16_kernel<128, 3>, so it is not kept.)
+template <int MT, bool TA, bool TB, int EPI>
 __global__ __launch_bounds__(768) void gemm_pstag_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B, bf16* C,
-                                                         int M, int N, int K, long lda, long ldb, long ldc, int tiles_m,
-                                                         int tiles_n, int group_m, EpiArgs ea) {
-  constexpr int BM = 256, NW = 8, NPROD = 4, NST = 3;
-  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;  // 48 KiB
-  constexpr int LOADS = (BM + BN) / (8 * NPROD);                                          // 12 per producer wave per tile
-  __shared__ __attribute__((aligned(16))) char smem[NST * STAGE + 8 * 2048];              // 144 KiB ring + 16 KiB store patches
+                                                         const bf16* R, int M, int N, int K, long lda, long ldb, long ldc,
+                                                         long ldr, int tiles_m, int tiles_n, int group_m, EpiArgs ea) {
+  static_assert(MT == 4 && (EPI == 0 || EPI == 3), "256 x 128 tile; plain or SwiGLU epilogue");
+  constexpr int BM = 64 * MT, NW = 8, NPROD = 4, NST = 3, DEPTH = NST - 1;
+  constexpr int WR = 16 * MT;                                                             // rows of C per compute wave
+  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;  // 48 / 32 KiB
+  constexpr int LOADS = (BM + BN) / (8 * NPROD);                                          // per producer wave per stage
+  constexpr int PATCH = 2048;                                                             // per compute wave
+  __shared__ __attribute__((aligned(16))) char smem[NST * STAGE + NW * PATCH];            // ring + store patches <= 160 KiB
   const int lane = lane_id();
   const int w = wave_id_uniform();
   const int ntiles = tiles_m * tiles_n;
@@ -554,8 +559,11 @@ __global__ __launch_bounds__(768) void gemm_pstag_kernel(const bf16* __restrict_
   // ------------------------------------------------------------------ producer waves 8..11: the operand stream
   // They alone issue LDS-DMA and wait on vmcnt, so the 8 compute waves never wait for memory: gfx950 counts loads
   // and stores in ONE in-order counter, and a compute wave that had just stored its finished tile would sit at its
-  // next counted wait until those stores were acknowledged (~5 us per tile measured).  Barrier count per wave:
-  // 1 + 2 per K-step + 1, the same in all three roles.
+  // next counted wait until those stores were acknowledged.  Barrier count per wave: 1 + 2 per K-step + 1, the same
+  // in all three roles.  Hazards (phase 2g = LOAD(g) of half 0, 2g+1 = LOAD(g) of half 1; a barrier between phases):
+  //   RAW  K-step g is first read in phase 2g; the producers retired it (counted vmcnt) by the end of phase 2g-2.
+  //   WAR  K-step g+DEPTH goes to the stage of K-step g-1, issued in phase 2g; the last reads of g-1 were issued in
+  //        phases 2g-2 / 2g-1 and completed (lgkmcnt(0)) before those phases' closing barriers.
   if (w >= NW) {
     const int pw = w - NW;
     FastStage<TA, BM, NPROD> fa;
@@ -590,17 +598,17 @@ __global__ __launch_bounds__(768) void gemm_pstag_kernel(const bf16* __restrict_
       if (++pf_k == nk) { pf_k = 0; pf_set(++pf_tile); }
     };
     pf_set(0);
-    pf_issue(smem);
-    pf_issue(smem + STAGE);
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) pf_issue(smem + d * STAGE);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    int nxt = 2;
+    int nxt = DEPTH;
     for (int g = 0; g < total; ++g) {
-      // phase 2g: K-step g+2 of the stream (steps past the end re-read the first origin and are never used) into the
-      // stage whose last readers (K-step g-1) finished before the barrier just passed; then K-step g+1 has landed
+      // phase 2g: K-step g+DEPTH of the stream (steps past the end re-read the first origin and are never used);
+      // then everything up to K-step g+1 has landed
       pf_issue(smem + nxt * STAGE);
-      nxt = (nxt == 2) ? 0 : nxt + 1;
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+      nxt = (nxt == NST - 1) ? 0 : nxt + 1;
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DEPTH - 1) * LOADS) : "memory");
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_s_barrier();  // phase 2g+1: nothing to do
     }
@@ -612,48 +620,52 @@ __global__ __launch_bounds__(768) void gemm_pstag_kernel(const bf16* __restrict_
   // ------------------------------------------------------------------ compute waves 0..7
   const int wm = w >> 1, wn = w & 1;
   const int half = w >> 2;
-  f32x4 acc[4][4];
+  f32x4 acc[MT][4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  __builtin_amdgcn_s_barrier();                 // the first two K-steps have landed
+  __builtin_amdgcn_s_barrier();                 // the first DEPTH K-steps have landed
   if (half == 1) __builtin_amdgcn_s_barrier();  // second half runs one phase behind
 
   int cur_i = 0, ck = 0, ctile = 0;
-  // EPI 0: the finished 64x64 block of this wave, rounded to bf16, leaves in 8 pieces of 8 rows x 128 B.  A piece goes
-  // through 2 KiB of LDS of the wave's own (XOR-swizzled 16-byte chunks) so that a store instruction writes whole
-  // 128-byte lines instead of 16 x 4 pieces of 32 B (-1.1 us per tile).  Spreading the pieces over the K-steps of the
-  // next tile (all CUs reach their tile boundary together) was measured and bought nothing.
-  bf16x4 pend[16];
-  int pend_m0 = 0, pend_n0 = 0;
-  char* ep = smem + NST * STAGE + w * 2048;
-  auto store_piece = [&](int q) {  // q = 2 i + hh (compile-time after unrolling)
-    const int i = q >> 1, hh = q & 1;
-    if (hh == 0) {
-      const int r = lane & 15, q4 = lane >> 4;
+  // The finished 16 x 64 blocks of this wave go through an LDS patch of the wave's own (XOR-swizzled 16-byte chunks) so
+  // that a store instruction writes whole 128-byte lines instead of 16 x 4 pieces of 32 B (-1.1 us per tile).
+  // Spreading the stores over the K-steps of the next tile (all CUs reach their tile boundary together) was
+  // measured: no gain.
+  char* ep = smem + NST * STAGE + w * PATCH;
+  auto store_rows = [&](const f32x4 (&a)[4], int gm0, int gn0) {  // a: this wave's 16 rows x 64 columns (j = 0..3)
+    const int r = lane & 15, q4 = lane >> 4;
+    {
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        *(bf16x4*)(ep + r * 128 + (((2 * j + (q4 >> 1)) ^ (r & 7)) << 4) + (q4 & 1) * 8) = pend[i * 4 + j];
+      for (int j = 0; j < 4; ++j) {
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (bf16)a[j][e];
+        *(bf16x4*)(ep + r * 128 + (((2 * j + (q4 >> 1)) ^ (r & 7)) << 4) + (q4 & 1) * 8) = o;
+      }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const int rr = hh * 8 + (lane >> 3), cc = lane & 7;
+        const bf16x8 v = *(const bf16x8*)(ep + rr * 128 + ((cc ^ (rr & 7)) << 4));
+        const int gmr = gm0 + rr, gn = gn0 + cc * 8;
+        if (gmr < M && gn < N) *(bf16x8*)(C + (long)gmr * ldc + gn) = v;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the patch is rewritten by the next block
     }
-    const int rr = hh * 8 + (lane >> 3), cc = lane & 7;
-    const bf16x8 v = *(const bf16x8*)(ep + rr * 128 + ((cc ^ (rr & 7)) << 4));
-    const int gmr = pend_m0 + i * 16 + rr, gn = pend_n0 + cc * 8;
-    if (gmr < M && gn < N) *(bf16x8*)(C + (long)gmr * ldc + gn) = v;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the patch may be overwritten by the next piece
   };
   for (int g = 0; g < total; ++g) {
     // ---- LOAD(g): fragments of K-step g
     const char* cur = smem + cur_i * STAGE;
-    bf16x8 af[2][4], bfr[2][4];
+    bf16x8 af[2][MT], bfr[2][4];
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       if constexpr (TA) {
-        load_frags_tr<BM, 4>(cur, wm * 64, kk, lane, af[kk]);
+        load_frags_tr<BM, MT>(cur, wm * WR, kk, lane, af[kk]);
       } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) af[kk][i] = load_frag<TA, BM>(cur, wm * 64 + i * 16, kk, lane);
+        for (int i = 0; i < MT; ++i) af[kk][i] = load_frag<TA, BM>(cur, wm * WR + i * 16, kk, lane);
       }
       if constexpr (EPI == 3) {
         static_assert(EPI != 3 || !TB, "SwiGLU epilogue: forward (NT) only");
@@ -676,19 +688,19 @@ __global__ __launch_bounds__(768) void gemm_pstag_kernel(const bf16* __restrict_
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(bfr[kk][j], af[kk][i], acc[i][j]);
     __builtin_amdgcn_s_setprio(0);
-    if (++ck == nk) {  // tile finished: park / store this wave's 64x64 block, clear, go on with the next tile
+    if (++ck == nk) {  // tile finished: this wave's block leaves, clear, go on with the next tile
       ck = 0;
       int tm, tn;
       origin(ctile++, tm, tn);
       const int m0 = tm * BM;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int gm = m0 + wm * 64 + i * 16 + (lane & 15);
+      for (int i = 0; i < MT; ++i) {
         if constexpr (EPI == 3) {
+          const int gm = m0 + wm * WR + i * 16 + (lane & 15);
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
             const int gc = tn * 64 + wn * 32 + j * 16 + (lane >> 4) * 4;  // column of act; gate at gc, up at I + gc
@@ -710,29 +722,16 @@ __global__ __launch_bounds__(768) void gemm_pstag_kernel(const bf16* __restrict_
             }
           }
         } else {
-          // park the block as bf16; it is stored a little per K-step during the next tile (store_piece below)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            bf16x4 o;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = (bf16)acc[i][j][e];
-            pend[i * 4 + j] = o;
-          }
+          store_rows(acc[i], m0 + wm * WR + i * 16, tn * BN + wn * 64);
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-      }
-      if constexpr (EPI == 0) {
-        pend_m0 = m0 + wm * 64;
-        pend_n0 = tn * BN + wn * 64;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) store_piece(q);
       }
     }
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    cur_i = (cur_i == 2) ? 0 : cur_i + 1;
+    cur_i = (cur_i == NST - 1) ? 0 : cur_i + 1;
   }
   if (half == 0) __builtin_amdgcn_s_barrier();  // re-align the halves
 }
@@ -932,8 +931,9 @@ int launch(const void* A, const void* B, void* C, const void* R, float* slabs, i
   do {                                                                                                               \
     if constexpr (BM == 256 && NST == 9 && (EPI == 0 || EPI == 3)) {                                                 \
       if (splits == 1 && tiles_m * tiles_n > persist_grid && persist_grid > 0) {                                       \
-        hipLaunchKernelGGL((gemm_pstag_kernel<TA, TB, EPI>), dim3(persist_grid), dim3(768), 0, st, (const bf16*)A,     \
-                           (const bf16*)B, (bf16*)C, M, N, K, lda, ldb, ldc, tiles_m, tiles_n, gm, ea);                \
+        hipLaunchKernelGGL((gemm_pstag_kernel<4, TA, TB, EPI>), dim3(persist_grid), dim3(768), 0, st, (const bf16*)A,  \
+                           (const bf16*)B, (bf16*)C, (const bf16*)R, M, N, K, lda, ldb, ldc, ldr, tiles_m, tiles_n,    \
+                           gm, ea);                                                                                    \
         break;                                                                                                         \
       }                                                                                                                \
     }                                                                                                                  \
