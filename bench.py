@@ -34,7 +34,7 @@ sys.path.insert(0, ROOT)
 MFMA_PEAK_TFLOPS = 2500.0  # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
 SPEECH_LO, VOCAB = 152927, 159488
-KERNEL_NAMES = {"gemm_nt_stag": "gemm_stag_kernel<false, false, EPI> (EPI 0 plain, 3 SwiGLU, 4 q/k-norm + RoPE epilogue)", "gemm_nt": "gemm_bf16_kernel<*,*,false,false,*>", "gemm_nn": "gemm_bf16_kernel<false,true,*>",
+KERNEL_NAMES = {"gemm_nt_stag": "staggered 256x128 forward GEMM family: gemm_pstag_kernel<4,false,false,EPI 0|3> (persistent: lm_heads, gate|up) + gemm_stag_kernel<false,false,EPI 4|0> (q|k|v)", "gemm_nt": "gemm_bf16_kernel<*,*,false,false,*>", "gemm_nn": "gemm_bf16_kernel<false,true,*>",
                 "gemm_tn": "gemm_bf16_kernel<true,true,*>"}
 
 

@@ -40,9 +40,9 @@ def main():
                      "--warmup 1 --no-cpu-baseline --no-prof --no-overlap` (scripts/profile_round.sh); counter unit KB; "
                      "FETCH_SIZE doubled (gfx950 reports half the bytes of 16-B/lane streaming reads, "
                      "MI355X_MICROARCH.md section HBM); per-launch averages over all launches of the named kernel(s)",
-           "gemm_nt_stag": summarise(r"gemm_stag_kernel<false, false, \d>",
-                                     "gemm_stag_kernel<false, false, EPI> (EPI 0 plain, 3 SwiGLU, 4 q/k-norm + RoPE)"),
-           "nt_gemm": summarise(r"gemm_(bf16|stag|ks)_kernel<(\d+, \d+, )?false, false",
+           "gemm_nt_stag": summarise(r"gemm_stag_kernel<false, false, \d>|gemm_pstag_kernel<4, false, false, \d>",
+                                     "gemm_pstag_kernel<4,false,false,EPI> + gemm_stag_kernel<false,false,EPI> (the staggered 256x128 forward family)"),
+           "nt_gemm": summarise(r"gemm_(bf16|stag|ks|pstag)_kernel<(\d+, \d+, |\d+, )?false, false",
                                 "every NT GEMM launch: gemm_bf16_kernel<*,*,false,false,*> + gemm_stag_kernel<false,false,*>")}
     json.dump(out, open(dst, "w"), indent=1)
     print(json.dumps(out, indent=1))
