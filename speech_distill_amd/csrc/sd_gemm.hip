@@ -1006,7 +1006,8 @@ int dispatch(const void* A, const void* B, void* C, const void* R, float* slabs,
     else if (tiles128 >= 256) { bm = 128; nst = 3; }
     else { bm = 64; nst = 3; }
   } else {  // TN: dW = dY^T . X (two warm activations)
-    if (tiles256 >= 1024) { bm = 256; nst = 9; }
+    static const long tn_stag_min = getenv("SD_TN_STAG_MIN") ? atol(getenv("SD_TN_STAG_MIN")) : 1024;  // A/B measurements
+    if (tiles256 >= tn_stag_min) { bm = 256; nst = 9; }
     else if (tiles128 >= 320) { bm = 128; nst = 2; }
     else { bm = 64; nst = blocks64 <= 320 ? 3 : 2; }
   }
