@@ -113,3 +113,28 @@ def test_matches_reference_value():
     v, i = L.extract_topk(t, 4, 32)
     ref = L.distill_loss(s, b["labels"], teacher_top_k_v=v, teacher_top_k_i=i, temperature=2.0, alpha=0.5)
     np.testing.assert_allclose(float(loss), float(ref[0]), rtol=1e-5)
+
+
+def test_loss_rows_selects_what_the_reference_keeps():
+    """ops.loss_rows == the reference's shift + valid mask (distillation_loss.py:31-45): position t < T-1 is kept iff
+    labels[t+1] != -100 (and mask[t+1]); the label a kept row predicts is labels[t+1]."""
+    from speech_distill_amd import ops
+    g = torch.Generator().manual_seed(9)
+    B, T = 3, 17
+    labels = torch.randint(0, 50, (B, T), generator=g)
+    labels[:, :5] = -100
+    labels[1, 9:] = -100
+    labels[2, 7] = -100
+    mask = (torch.rand(B, T, generator=g) > 0.3).long()
+    for m in (None, mask):
+        rows, lab = ops.loss_rows(labels, m)
+        y = labels[:, 1:].reshape(-1)
+        valid = y != -100
+        if m is not None:
+            valid &= m[:, 1:].reshape(-1).bool()
+        # flat index into the UNshifted [B, T] grid of the shifted position (b, t)
+        want = torch.tensor([b * T + t for b in range(B) for t in range(T - 1)])[valid]
+        assert torch.equal(rows, want)
+        assert torch.equal(lab, y[valid])
+    rows, lab = ops.loss_rows(torch.full((2, 4), -100))
+    assert rows.numel() == 0 and lab.numel() == 0
