@@ -98,6 +98,7 @@ def main():
     ap.add_argument("--full-head", action="store_true",
                     help="apply lm_head / top-K / loss to all B*T rows (default: only the rows the loss reads, as "
                          "DistillationTrainer.compute_loss does on training steps)")
+    ap.add_argument("--phases", action="store_true", help="print the wall time of the phases of a step (stderr)")
     ap.add_argument("--no-overlap", action="store_true", help="single stream everywhere (clean per-kernel profiles)")
     args = ap.parse_args()
 
@@ -148,9 +149,18 @@ def main():
                            logit_rows=rows).logits                                          # train.py:60-69
         return ops.logsoftmax_topk(t_logits, args.top_k, VOCAB)                             # train.py:80-91
 
+    phase_ev = []
+
+    def mark():
+        if args.phases:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            phase_ev.append(e)
+
     def step(overlap=True):
         # the same sequence as speech_distill_amd.trainer.DistillationTrainer.compute_loss on a training step
         student.zero_grad()
+        mark()
         rows = row_labels = None
         if not args.full_head:  # rows whose shifted label is not -100 (distillation_loss.py:31-45); one host sync
             rows, row_labels = ops.loss_rows(batch["labels"])
@@ -163,13 +173,17 @@ def main():
                     tv, ti = teacher_topk(rows)
         logits = student(input_ids=batch["input_ids"], attention_mask=batch["attention_mask"],
                          labels=batch["labels"], logit_rows=rows).logits                    # train.py:54
+        mark()
         if side is not None and overlap:
             torch.cuda.current_stream().wait_stream(side)
+        mark()
         if rows is None:
             total, task, distill, teach = loss_fn(logits, batch["labels"], teacher_top_k_v=tv, teacher_top_k_i=ti)
         else:
             total, task, distill, teach = loss_fn.forward_rows(logits, row_labels, teacher_top_k_v=tv, teacher_top_k_i=ti)
+        mark()
         total.backward()                                                                    # HF trainer.py:1961
+        mark()
         return total, task, distill, teach
 
     def barrier():
@@ -185,6 +199,17 @@ def main():
         out = step()
     barrier()
     dt = time.perf_counter() - t0
+    if args.phases and rank == 0:
+        import sys
+        n = 5
+        ev = phase_ev[-n * args.steps:] if len(phase_ev) >= n * args.steps else phase_ev
+        names = ["student fwd (teacher beside it)", "wait for teacher + top-K", "loss fwd", "backward"]
+        acc = [0.0] * 4
+        for k in range(0, len(ev) - n + 1, n):
+            for j in range(4):
+                acc[j] += ev[k + j].elapsed_time(ev[k + j + 1])
+        for j in range(4):
+            print(f"[phase] {names[j]:34s} {acc[j] / max(1, len(ev) // n):7.3f} ms", file=sys.stderr)
     # Per-kernel durations: the SAME K steps again, immediately after the timed region, with HIP events
     # recorded on the launch stream around every launch.  Kept out of the timed region because ~2 000
     # event records per step stretch the step by ~20 % (measured 39.8 vs 32.9 ms) and would understate `value`.

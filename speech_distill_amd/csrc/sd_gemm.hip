@@ -1065,9 +1065,17 @@ extern "C" int sd_gemm_splitk_plan(int M, int N, int K) {
   const int kt = (K + BK - 1) / BK;
   static const int min_kt = getenv("SD_SPLITK_MIN_KT") ? atoi(getenv("SD_SPLITK_MIN_KT")) : 96;  // A/B measurements
   if (tiles >= 256 || kt < min_kt) return 1;
-  static const int target = getenv("SD_SPLITK_TARGET") ? atoi(getenv("SD_SPLITK_TARGET")) : 256;
-  int s = (int)(((kt >= 256 ? 512 : target) + tiles - 1) / tiles);
-  if (s > 8) s = 8;
+  // The slice count that fills whole rounds of 256 workgroups best (fewest slices on a tie: every slice is another
+  // fp32 slab; a slice keeps at least 24 K-steps).  48 tiles (lm_head dX on R = 1536 rows) -> 5 slices = 240
+  // workgroups, not 8 = 384 = 1.5 rounds; 64 tiles -> 4.
+  const int cmax = kt / 24 < 8 ? kt / 24 : 8;
+  int s = 1;
+  double best = (double)tiles / 256.0;
+  for (int c = 2; c <= cmax; ++c) {
+    const long wg = tiles * c;
+    const double eff = (double)wg / (double)(((wg + 255) / 256) * 256);
+    if (eff > best + 1e-9) { best = eff; s = c; }
+  }
   return s < 1 ? 1 : s;
 }
 
