@@ -201,6 +201,12 @@ def main():
     dt = time.perf_counter() - t0
     if args.phases and rank == 0:
         import sys
+        torch.cuda.synchronize()
+        t_enq = time.perf_counter()
+        step()
+        t_enq = time.perf_counter() - t_enq
+        torch.cuda.synchronize()
+        print(f"[phase] host time to enqueue one step (GPU idle at start): {t_enq * 1e3:.3f} ms", file=sys.stderr)
         n = 5
         ev = phase_ev[-n * args.steps:] if len(phase_ev) >= n * args.steps else phase_ev
         names = ["student fwd (teacher beside it)", "wait for teacher + top-K", "loss fwd", "backward"]

@@ -58,6 +58,10 @@ int sd_gemm_bf16_splitk_partial(const void* A, const void* B, void* C, int M, in
  * sd_gemm_swiglu: act [M,I] = silu(x Wg^T) * (x Wu^T), wgu = [gate rows | up rows] [2I,K]; gu_out [M,2I] nullable (HF:81-83).
  * sd_gemm_qkv_rope: raw q|k|v [M,(Hq+2Hkv)*128] plus RMS-normalised + RoPE-rotated q|k [M,(Hq+Hkv)*128] (HF:252-257). */
 int sd_gemm_swiglu(const void* x, const void* wgu, void* gu_out, void* act_out, int M, int I, int K, void* stream);
+/* backward twin: d(gate|up) [M,2I] = SwiGLU'(gate_up) applied to d(act) = dy [M,H] . W_down [H,I], in the epilogue of
+ * that GEMM (d(act) is never stored); equals sd_gemm_bf16 (NN) + sd_swiglu_bwd bit for bit. */
+int sd_gemm_swiglu_bwd(const void* dy, const void* wdown, const void* gate_up, void* dgate_up, int M, int I, int H,
+                       void* stream);
 int sd_gemm_qkv_rope(const void* x, const void* wqkv, void* qkv_out, void* qk_out, const void* q_gain, const void* k_gain,
                      const void* cos_tab, const void* sin_tab, int M, int T, int Hq, int Hkv, int K, float eps,
                      void* stream);

@@ -146,6 +146,8 @@ SD_DEV void load_frags_tr(const char* lds_tile, int row_base, int kk, int lane, 
 //          is written to out2 [M,I], gate|up (needed by the backward) to C [M,2I] when C != nullptr.
 //   EPI 4 (q|k|v GEMM + per-head RMSNorm + rotate-half RoPE, HF:252-257,121-170): one 128-column tile is exactly one
 //          head; raw q|k|v go to C, normalised + rotated q|k heads to out2 [M,(Hq+Hkv)*128].
+//   EPI 5 (down-projection dX GEMM + SwiGLU backward, HF:81-83 run backwards): the tile is d(act); g0 = gate|up of the
+//          forward [M,2I] (row stride ld2), out2 = d(gate|up) [M,2I]; d(act) itself is not stored.
 struct EpiArgs {
   bf16* out2;
   long ld2;
@@ -161,15 +163,15 @@ struct EpiArgs {
 template <int EPI, int BM, int NTHR>
 struct EpiPre {
   static constexpr int IT = BM * 16 / NTHR;
-  bf16x8 a[(EPI == 1 || EPI == 4) ? IT : 1];
-  bf16x8 b[EPI == 4 ? IT : 1];
+  bf16x8 a[(EPI == 1 || EPI == 4 || EPI == 5) ? IT : 1];
+  bf16x8 b[(EPI == 4 || EPI == 5) ? IT : 1];
   bf16x8 gain;
 };
 
 template <int EPI, int BM, int NTHR>
 SD_DEV void epi_preload(EpiPre<EPI, BM, NTHR>& pre, const bf16* R, const EpiArgs& ea, int M, int N, long ldr, int m0,
                         int n0, int tn) {
-  if constexpr (EPI == 1 || EPI == 4) {
+  if constexpr (EPI == 1 || EPI == 4 || EPI == 5) {
 #pragma unroll
     for (int it = 0; it < BM * 16 / NTHR; ++it) {
       const int q = it * NTHR + threadIdx.x;
@@ -179,6 +181,11 @@ SD_DEV void epi_preload(EpiPre<EPI, BM, NTHR>& pre, const bf16* R, const EpiArgs
         const bool ok = gm < M && gn < N;
         bf16x8 z = {};
         pre.a[it] = ok ? *(const bf16x8*)(R + (long)gm * ldr + gn) : z;
+      } else if constexpr (EPI == 5) {  // gate and up of the forward at this (row, 8 columns)
+        const bool ok = gm < M && gn < N;
+        bf16x8 z = {};
+        pre.a[it] = ok ? *(const bf16x8*)(ea.g0 + (long)gm * ea.ld2 + gn) : z;
+        pre.b[it] = ok ? *(const bf16x8*)(ea.g0 + (long)gm * ea.ld2 + ea.I + gn) : z;
       } else {
         const int gmc = gm < M ? gm : M - 1;
         const int t = gmc % ea.T;
@@ -229,6 +236,20 @@ SD_DEV void write_out(const float* cs, bf16* C, const EpiPre<EPI, BM, NTHR>& pre
           *(bf16x8*)(C + (long)gm * ldc + ea.I + col) = ub;
         }
         *(bf16x8*)(ea.out2 + (long)gm * ea.ld2 + col) = ab;
+      }
+    } else if constexpr (EPI == 5) {
+      // SwiGLU backward on d(act) = this tile (rounded to bf16 first, as the unfused pair stores it): d(gate), d(up)
+      if (ok) {
+        bf16x8 dg, du;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float d = (float)(bf16)v[e], g = (float)pre.a[it][e], u = (float)pre.b[it][e];
+          const float sg = 1.f / (1.f + __expf(-g));
+          du[e] = (bf16)(d * g * sg);
+          dg[e] = (bf16)(d * u * sg * (1.f + g * (1.f - sg)));
+        }
+        *(bf16x8*)(ea.out2 + (long)gm * ea.ld2 + gn) = dg;
+        *(bf16x8*)(ea.out2 + (long)gm * ea.ld2 + ea.I + gn) = du;
       }
     } else if constexpr (EPI == 4) {
       bf16x8 raw;
@@ -957,6 +978,9 @@ int launch(const void* A, const void* B, void* C, const void* R, float* slabs, i
     if (epi_kind == 3) { if (!fast) return SD_ERR_UNSUPPORTED; SD_GEMM_GO(3); SD_CHECK_LAUNCH(); return 0; }
     if (epi_kind == 4) { if (!fast) return SD_ERR_UNSUPPORTED; SD_GEMM_GO(4); SD_CHECK_LAUNCH(); return 0; }
   }
+  if constexpr (!TA && TB) {
+    if (epi_kind == 5) { if (!fast) return SD_ERR_UNSUPPORTED; SD_GEMM_GO(5); SD_CHECK_LAUNCH(); return 0; }
+  }
   if (splits > 1) SD_GEMM_GO(2);
   else if (R) SD_GEMM_GO(1);
   else SD_GEMM_GO(0);
@@ -1109,6 +1133,21 @@ extern "C" int sd_gemm_bf16_splitk_partial(const void* A, const void* B, void* C
                           (hipStream_t)stream);
   g_skip_reduce = false;
   return rc;
+}
+
+// dX of the down projection with the SwiGLU backward in its epilogue: d(gate|up) [M,2I] from dy [M,h], W_down [h,I]
+// and the forward's gate|up [M,2I]; d(act) is never stored.  Bit-identical to sd_gemm_bf16 (NN) + sd_swiglu_bwd.
+extern "C" int sd_gemm_swiglu_bwd(const void* dy, const void* wdown, const void* gate_up, void* dgate_up, int M, int I,
+                                  int H, void* stream) {
+  if (M <= 0 || I <= 0 || H <= 0 || (I & 7) || (H & 7)) return SD_ERR_UNSUPPORTED;
+  if (((uintptr_t)dy | (uintptr_t)wdown | (uintptr_t)gate_up | (uintptr_t)dgate_up) & 15) return SD_ERR_ALIGN;
+  EpiArgs ea{};
+  ea.out2 = (bf16*)dgate_up;
+  ea.ld2 = 2L * I;
+  ea.I = I;
+  ea.g0 = (const bf16*)gate_up;
+  // NN: C[M,I] = dy[M,H] . W[H,I]; C itself (d act) is not written: the epilogue needs a non-null C only for alignment checks
+  return dispatch(dy, wdown, dgate_up, nullptr, nullptr, 1, M, I, H, H, I, I, 0, 0, 1, (hipStream_t)stream, 5, &ea);
 }
 
 // gate|up projection with SwiGLU fused into the epilogue (HF:81-83): act [M,I] = silu(x Wg^T) * (x Wu^T);

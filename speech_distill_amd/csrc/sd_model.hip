@@ -251,8 +251,16 @@ extern "C" int sd_qwen3_backward_rows(const sd_qwen3_dims* d, const sd_qwen3_par
     // MLP
     SIGNAL(0);  // dx_a final
     RUN(sd_gemm_bf16(b.dx_a, a.act, gw.wdown, ACC(gw.wdown), s.h, s.I, s.M, s.h, s.I, s.I, s.I, 1, 1, wstream));
-    RUN(sd_gemm_bf16(b.dx_a, w.wdown, b.dact, nullptr, s.M, s.I, s.h, s.h, s.I, s.I, 0, 0, 1, stream));
-    RUN(sd_swiglu_bwd(b.dact, a.gu, b.dgu, s.M, s.I, stream));
+    // d(act) = dx_a . W_down with the SwiGLU backward in the epilogue: d(act) itself never reaches HBM
+    {
+      const int rc = sd_gemm_swiglu_bwd(b.dx_a, w.wdown, a.gu, b.dgu, s.M, s.I, s.h, stream);
+      if (rc == SD_ERR_UNSUPPORTED) {
+        RUN(sd_gemm_bf16(b.dx_a, w.wdown, b.dact, nullptr, s.M, s.I, s.h, s.h, s.I, s.I, 0, 0, 1, stream));
+        RUN(sd_swiglu_bwd(b.dact, a.gu, b.dgu, s.M, s.I, stream));
+      } else if (rc) {
+        return rc;
+      }
+    }
     SIGNAL(1);  // dgu final
     RUN(sd_gemm_bf16_splitk_partial(b.dgu, w.wgu, b.dxn, s.M, s.h, 2 * s.I, 2 * s.I, s.h, s.h, 0, 1, b.ws_splitk,
                                     b.splitk_bytes, &nsp, stream));

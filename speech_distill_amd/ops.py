@@ -239,6 +239,17 @@ class KDLossFn(torch.autograd.Function):
         return grad, None, None, None, None, None, None, None, None
 
 
+def gemm_swiglu_bwd(dy, wdown, gate_up):
+    """d(gate|up) [M,2I] from dy [M,h], W_down [h,I] (torch layout [out=h, in=I]) and the forward's gate|up."""
+    _need(dy, torch.bfloat16, "dy")
+    M, H = dy.shape
+    I = wdown.shape[1]
+    out = torch.empty(M, 2 * I, dtype=torch.bfloat16, device=dy.device)
+    check(load_lib().sd_gemm_swiglu_bwd(dy.data_ptr(), wdown.data_ptr(), gate_up.data_ptr(), out.data_ptr(), M, I, H,
+                                        _stream()), "sd_gemm_swiglu_bwd")
+    return out
+
+
 class KDLossRowsFn(torch.autograd.Function):
     """The same loss on rows the caller has already shifted and selected (distillation_loss.py:31-45 done by the
     caller): student_logits [R,V], row_labels [R], teacher_logits [R,V] or (top_v, top_i) [R,K]."""

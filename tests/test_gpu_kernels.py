@@ -194,6 +194,25 @@ def test_gemm_persistent_swiglu(ops):
     assert torch.equal(act, act_ref) and torch.equal(act2, act_ref)
 
 
+@pytest.mark.parametrize("bm,nst", [(0, 0), (64, 3), (128, 3), (256, 9)])
+def test_gemm_swiglu_bwd_epilogue_equals_the_separate_kernels(ops, bm, nst):
+    """down-projection dX GEMM + SwiGLU backward in its epilogue == sd_gemm_bf16 (NN) + sd_swiglu_bwd, bit for bit."""
+    g = torch.Generator().manual_seed(17)
+    M, H, I = 300, 256, 520
+    dy = to_dev(bf(torch.randn(M, H, generator=g)))
+    wdown = to_dev(bf(torch.randn(H, I, generator=g) * 0.1))
+    gu = to_dev(bf(torch.randn(M, 2 * I, generator=g)))
+    dact = ops.gemm(dy, wdown, False, True)
+    ref = ops.swiglu_bwd(dact, gu)
+    lib = ops.load_lib()
+    lib.sd_gemm_force_variant(bm, nst)
+    try:
+        got = ops.gemm_swiglu_bwd(dy, wdown, gu)
+    finally:
+        lib.sd_gemm_force_variant(0, 0)
+    assert torch.equal(got, ref), float((got.float() - ref.float()).abs().max())
+
+
 def test_gemm_split_k(ops):
     """few tiles + long K -> fp32 slabs + fixed-order reduce (the lm_head dX shape class)."""
     g = torch.Generator().manual_seed(6)
