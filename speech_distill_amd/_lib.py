@@ -29,6 +29,11 @@ class Dims(C.Structure):
                 ("eps", C.c_float), ("pad_", C.c_int32)]
 
 
+class GemmProblem(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p), ("lda", C.c_int64), ("ldb", C.c_int64),
+                ("ldc", C.c_int64), ("M", C.c_int32), ("N", C.c_int32)]
+
+
 class Layer(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("wqkv", "wo", "wgu", "wdown", "q_gain", "k_gain", "ln1", "ln2")]
 
@@ -75,6 +80,7 @@ PROTOTYPES = {
     "sd_kdloss_stats_bytes": (_i64, [_i, _i]),
     "sd_kdloss_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _i, _vp]),
     "sd_kdloss_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _i, _vp]),
+    "sd_gemm_grouped_tn": (_i, [_vp, _i, _i, _vp]),
     "sd_gemm_swiglu_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "sd_kdloss_fwd_rows": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _vp]),
     "sd_kdloss_bwd_rows": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _vp]),

@@ -758,6 +758,167 @@ __global__ __launch_bounds__(768) void gemm_pstag_kernel(const bf16* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Grouped form of the persistent kernel for the weight gradients of one decoder layer: up to 4 independent problems
+// C_p[M_p,N_p] = A_p^T . B_p with a common contraction length K (the tokens of the micro-batch), both operands stored
+// [K][rows] (dY and X as they lie in HBM).  Separately the four dW GEMMs of a Qwen3 layer have 64-192 tiles of
+// 256x128 each, so none of them fills 256 CUs with the big tile and each pays its own launch and ramp; as one
+// persistent launch their 480 tiles are one stream of work (1.9 tiles per CU).  Same 12-wave structure and hazard
+// argument as gemm_pstag_kernel; a tile id is looked up in the problem table (kernel argument) by both roles.
+struct GroupArgs {
+  const bf16* A[4];
+  const bf16* B[4];
+  bf16* C[4];
+  long lda[4], ldb[4], ldc[4];
+  int M[4], N[4], tiles_m[4], tiles_n[4];
+  int start[5];  // first global tile id of each problem; start[n] = total
+  int n;
+};
+
+__global__ __launch_bounds__(768) void gemm_pgroup_tn_kernel(GroupArgs ga, int K, int group_m) {
+  constexpr int BM = 256, NW = 8, NPROD = 4, NST = 3, DEPTH = NST - 1;
+  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;  // 48 KiB
+  constexpr int LOADS = (BM + BN) / (8 * NPROD);
+  constexpr int PATCH = 2048;
+  __shared__ __attribute__((aligned(16))) char smem[NST * STAGE + NW * PATCH];
+  const int lane = lane_id();
+  const int w = wave_id_uniform();
+  const int ntiles = ga.start[ga.n];
+  const int nk = (K + BK - 1) / BK;
+  const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int total = my_tiles * nk;
+  // (problem, tile row, tile column) of my idx-th tile
+  auto locate = [&](int idx, int& p, int& tm, int& tn) {
+    const int t = xcd_remap((int)blockIdx.x + idx * (int)gridDim.x, ntiles);
+    p = 0;
+#pragma unroll
+    for (int q = 1; q < 4; ++q)
+      if (q < ga.n && t >= ga.start[q]) p = q;
+    p = __builtin_amdgcn_readfirstlane(p);
+    const int gm = group_m < ga.tiles_m[p] ? group_m : ga.tiles_m[p];
+    tile_coords(t - ga.start[p], ga.tiles_m[p], ga.tiles_n[p], gm, tm, tn);
+  };
+
+  if (w >= NW) {  // ------------------------------------------------------------ producer waves
+    const int pw = w - NW;
+    FastStage<true, BM, NPROD> fa;
+    FastStage<true, BN, NPROD> fb;
+    int pf_tile = 0, pf_k = 0;
+    unsigned pf_a = 0, pf_b = 0;
+    (void)pf_a; (void)pf_b;
+    auto pf_set = [&](int idx) {
+      int p = 0, tm = 0, tn = 0;
+      if (idx < my_tiles) locate(idx, p, tm, tn);
+      fa.init(ga.A[p], ga.lda[p], 0, (unsigned)(((long)(K - 1) * ga.lda[p] + ga.M[p]) * 2), pw, lane);
+      fb.init(ga.B[p], ga.ldb[p], 0, (unsigned)(((long)(K - 1) * ga.ldb[p] + ga.N[p]) * 2), pw, lane);
+      pf_a = (unsigned)((long)tm * BM * 2);
+      pf_b = (unsigned)((long)tn * BN * 2);
+    };
+    auto pf_issue = [&](char* stage) {
+#if defined(__HIP_DEVICE_COMPILE__)
+      const int sa = (int)(pf_a + (unsigned)(pf_k * BK) * (unsigned)fa.kstep);
+      const int sb = (int)(pf_b + (unsigned)(pf_k * BK) * (unsigned)fb.kstep);
+#pragma unroll
+      for (int i = 0; i < FastStage<true, BM, NPROD>::NI; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+            fa.rsrc, (SD_LDS void*)(stage + (pw * FastStage<true, BM, NPROD>::NI + i) * 1024), 16, fa.voff[i], sa, 0, 0);
+#pragma unroll
+      for (int i = 0; i < FastStage<true, BN, NPROD>::NI; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+            fb.rsrc, (SD_LDS void*)(stage + A_BYTES + (pw * FastStage<true, BN, NPROD>::NI + i) * 1024), 16, fb.voff[i],
+            sb, 0, 0);
+#endif
+      if (++pf_k == nk) { pf_k = 0; pf_set(++pf_tile); }
+    };
+    pf_set(0);
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) pf_issue(smem + d * STAGE);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    int nxt = DEPTH;
+    for (int g = 0; g < total; ++g) {
+      pf_issue(smem + nxt * STAGE);
+      nxt = (nxt == NST - 1) ? 0 : nxt + 1;
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DEPTH - 1) * LOADS) : "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_s_barrier();
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return;
+  }
+
+  // ---------------------------------------------------------------------------- compute waves
+  const int wm = w >> 1, wn = w & 1;
+  const int half = w >> 2;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  __builtin_amdgcn_s_barrier();
+  if (half == 1) __builtin_amdgcn_s_barrier();
+
+  int cur_i = 0, ck = 0, ctile = 0;
+  char* ep = smem + NST * STAGE + w * PATCH;
+  for (int g = 0; g < total; ++g) {
+    const char* cur = smem + cur_i * STAGE;
+    bf16x8 af[2][4], bfr[2][4];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      load_frags_tr<BM, 4>(cur, wm * 64, kk, lane, af[kk]);
+      load_frags_tr<BN, 4>(cur + A_BYTES, wn * 64, kk, lane, bfr[kk]);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(bfr[kk][j], af[kk][i], acc[i][j]);
+    __builtin_amdgcn_s_setprio(0);
+    if (++ck == nk) {
+      ck = 0;
+      int p, tm, tn;
+      locate(ctile++, p, tm, tn);
+      bf16* C = ga.C[p];
+      const long ldc = ga.ldc[p];
+      const int M = ga.M[p], N = ga.N[p];
+      const int r = lane & 15, q4 = lane >> 4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int gm0 = tm * BM + wm * 64 + i * 16, gn0 = tn * BN + wn * 64;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          bf16x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = (bf16)acc[i][j][e];
+          *(bf16x4*)(ep + r * 128 + (((2 * j + (q4 >> 1)) ^ (r & 7)) << 4) + (q4 & 1) * 8) = o;
+          acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          const int rr = hh * 8 + (lane >> 3), cc = lane & 7;
+          const bf16x8 v = *(const bf16x8*)(ep + rr * 128 + ((cc ^ (rr & 7)) << 4));
+          const int gmr = gm0 + rr, gn = gn0 + cc * 8;
+          if (gmr < M && gn < N) *(bf16x8*)(C + (long)gmr * ldc + gn) = v;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    cur_i = (cur_i == NST - 1) ? 0 : cur_i + 1;
+  }
+  if (half == 0) __builtin_amdgcn_s_barrier();
+}
+
+// ---------------------------------------------------------------------------------------------------
 // K-split staggered 64x128x64 kernel (8 waves) for GEMMs with few output tiles and a long K (N = hidden: o / down
 // forward, every dX; 128-256 tiles of 64x128 on 256 CUs).  With one 4-wave workgroup per CU there is one wave per
 // SIMD and its DMA issue, LDS reads and MFMAs run back to back (~1 270 cycles per K-step for 256 cycles of MFMA).
@@ -1133,6 +1294,39 @@ extern "C" int sd_gemm_bf16_splitk_partial(const void* A, const void* B, void* C
                           (hipStream_t)stream);
   g_skip_reduce = false;
   return rc;
+}
+
+// Weight gradients of one layer in one persistent launch: C_p [M_p,N_p] = A_p^T . B_p for p < n <= 4, A_p [K,M_p]
+// (row stride lda), B_p [K,N_p], common K.  SD_ERR_UNSUPPORTED when a problem does not fit the descriptor staging.
+extern "C" int sd_gemm_grouped_tn(const sd_gemm_problem* probs, int n, int K, void* stream) {
+  if (n <= 0 || n > 4 || K <= 0 || !probs) return SD_ERR_SHAPE;
+  GroupArgs ga{};
+  int start = 0;
+  double flops = 0.0;
+  for (int p = 0; p < n; ++p) {
+    const sd_gemm_problem& q = probs[p];
+    if (q.M <= 0 || q.N <= 0 || (q.M & 7) || (q.N & 7) || ((q.lda | q.ldb | q.ldc) & 7)) return SD_ERR_ALIGN;
+    if (((uintptr_t)q.A | (uintptr_t)q.B | (uintptr_t)q.C) & 15) return SD_ERR_ALIGN;
+    if (((long)K * q.lda + q.M) * 2 >= 0x70000000L || ((long)K * q.ldb + q.N) * 2 >= 0x70000000L) return SD_ERR_UNSUPPORTED;
+    ga.A[p] = (const bf16*)q.A; ga.B[p] = (const bf16*)q.B; ga.C[p] = (bf16*)q.C;
+    ga.lda[p] = q.lda; ga.ldb[p] = q.ldb; ga.ldc[p] = q.ldc;
+    ga.M[p] = q.M; ga.N[p] = q.N;
+    ga.tiles_m[p] = (q.M + 255) / 256; ga.tiles_n[p] = (q.N + BN - 1) / BN;
+    ga.start[p] = start;
+    start += ga.tiles_m[p] * ga.tiles_n[p];
+    flops += 2.0 * q.M * q.N * K;
+  }
+  for (int p = n; p <= 4; ++p) ga.start[p] = start;
+  ga.n = n;
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+    return SD_ERR_UNSUPPORTED;
+  cus &= ~7;
+  if (cus <= 0) return SD_ERR_UNSUPPORTED;
+  SdProfScope prof(SD_K_GEMM_TN, flops, (hipStream_t)stream);
+  hipLaunchKernelGGL(gemm_pgroup_tn_kernel, dim3(start < cus ? start : cus), dim3(768), 0, (hipStream_t)stream, ga, K, 4);
+  SD_CHECK_LAUNCH();
+  return 0;
 }
 
 // dX of the down projection with the SwiGLU backward in its epilogue: d(gate|up) [M,2I] from dy [M,h], W_down [h,I]

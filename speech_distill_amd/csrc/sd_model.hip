@@ -47,23 +47,29 @@ LayerActs carve(const Sizes& s, char* p) {
   return a;
 }
 
+// The buffers a layer's weight-gradient GEMMs read (dxa = gradient entering the layer, dgu, dxb, dqkv) and the gain
+// partials reduced on the side stream exist twice, used by layer parity: the grouped dW launch of layer l runs on
+// the side stream under the dX chain of layer l-1, which writes the other set.
 struct BwdScratch {
-  char *dx_a, *dx_b, *dxn, *dqkv, *dqk, *dao, *delta, *dgu, *dact, *ws_norm, *ws_norm2, *ws_qk, *ws_splitk;
+  char *dxa[2], *dxb[2], *dqkv[2], *dgu[2], *ws_norm2[2], *ws_qk[2];
+  char *dxn, *dqk, *dao, *delta, *dact, *ws_norm, *ws_splitk;
   int64_t total, splitk_bytes;
   BwdScratch(const Sizes& s, char* p) {
     char* p0 = p;
-    dx_a = p; p += s.x;
-    dx_b = p; p += s.x;
+    for (int i = 0; i < 2; ++i) {
+      dxa[i] = p; p += s.x;
+      dxb[i] = p; p += s.x;
+      dqkv[i] = p; p += s.qkv;
+      dgu[i] = p; p += s.gu;
+      ws_norm2[i] = p; p += al(sd_rmsnorm_bwd_workspace_bytes(s.M, s.h));
+      ws_qk[i] = p; p += al(sd_qknorm_rope_bwd_workspace_bytes(s.M, s.Hq, s.Hkv));
+    }
     dxn = p; p += s.x;
-    dqkv = p; p += s.qkv;
     dqk = p; p += s.qk;
     dao = p; p += s.ao;
     delta = p; p += s.lse;
-    dgu = p; p += s.gu;
     dact = p; p += s.act;
     ws_norm = p; p += al(sd_rmsnorm_bwd_workspace_bytes(s.M, s.h));
-    ws_norm2 = p; p += al(sd_rmsnorm_bwd_workspace_bytes(s.M, s.h));
-    ws_qk = p; p += al(sd_qknorm_rope_bwd_workspace_bytes(s.M, s.Hq, s.Hkv));
     splitk_bytes = sd_gemm_splitk_workspace_bytes(s.M, s.h, s.V);
     for (int k : {s.QKV, 2 * s.I, s.QD, s.I}) {
       const int64_t b1 = sd_gemm_splitk_workspace_bytes(s.M, s.h, k);
@@ -155,7 +161,9 @@ extern "C" int sd_qwen3_forward_rows(const sd_qwen3_dims* d, const sd_qwen3_para
     // gate|up projection: SwiGLU runs in the GEMM epilogue when gate|up need not be kept (no backward follows:
     // the frozen teacher).  With the 2*I-wide store as well the fused epilogue is no faster than the separate
     // elementwise pass (tests/bench_fused.py), so the student keeps the two-kernel form.
-    rc = save ? SD_ERR_UNSUPPORTED : sd_gemm_swiglu(a.xn2, w.wgu, nullptr, a.act, s.M, s.I, s.h, stream);
+    static const int fuse_student = getenv("SD_FUSE_STUDENT_SWIGLU") ? atoi(getenv("SD_FUSE_STUDENT_SWIGLU")) : 0;  // A/B
+    rc = (save && !fuse_student) ? SD_ERR_UNSUPPORTED
+                                 : sd_gemm_swiglu(a.xn2, w.wgu, save ? a.gu : nullptr, a.act, s.M, s.I, s.h, stream);
     if (rc == SD_ERR_UNSUPPORTED) {
       RUN(sd_gemm_bf16(a.xn2, w.wgu, a.gu, nullptr, s.M, 2 * s.I, s.h, s.h, s.h, 2 * s.I, 0, 0, 0, stream));
       RUN(sd_swiglu_fwd(a.gu, a.act, s.M, s.I, stream));
@@ -207,8 +215,8 @@ extern "C" int sd_qwen3_backward_rows(const sd_qwen3_dims* d, const sd_qwen3_par
   char* xn_rows = xn_f + s.x;
   const int acc = accumulate ? 1 : 0;
 #define ACC(ptr) (acc ? (const void*)(ptr) : (const void*)nullptr)
-  // A/B switch for measurements: SD_OVERLAP_MASK bit0 lm_head dW, bit1 gain reduces, bit2 attention dQ (default all on)
-  static const int ovl = getenv("SD_OVERLAP_MASK") ? atoi(getenv("SD_OVERLAP_MASK")) : 7;
+  // A/B switch for measurements: SD_OVERLAP_MASK bit0 lm_head dW, bit1 gain reduces, bit2 attention dQ, bit3 grouped per-layer dW (default all on)
+  static const int ovl = getenv("SD_OVERLAP_MASK") ? atoi(getenv("SD_OVERLAP_MASK")) : 15;
   hipStream_t s1 = (hipStream_t)stream, s2 = (hipStream_t)side_stream;
   if (s2 && !ensure_events()) return SD_ERR_WORKSPACE;
   void* wstream = s2 ? side_stream : stream;  // where weight-gradient GEMMs go
@@ -217,15 +225,16 @@ extern "C" int sd_qwen3_backward_rows(const sd_qwen3_dims* d, const sd_qwen3_par
 #define JOIN() do { if (s2) { if (hipEventRecord(g_ev[7], s2) != hipSuccess || hipStreamWaitEvent(s1, g_ev[7], 0) != hipSuccess) return SD_ERR_WORKSPACE; } } while (0)
 
   // lm_head: dxn = dlogits . W ; dW (+)= dlogits^T . xn_f
+  const int top = (s.L - 1) & 1;  // buffer set of the last layer (the first one the backward visits)
   SIGNAL(0);  // dlogits (produced on `stream` by the caller) is final: lm_head dW runs beside lm_head dX
   int nsp = 1;
   if (head_rows) {
     // dlogits holds only the n_head_rows rows the forward produced; every other row of d(xn_f) is zero
     RUN(sd_gemm_bf16(dlogits, xn_rows, g->lm_head, ACC(g->lm_head), s.V, s.h, n_head_rows, s.V, s.h, s.h, s.h, 1, 1,
                      (ovl & 1) ? wstream : stream));
-    RUN(sd_gemm_bf16_splitk(dlogits, p->lm_head, b.dx_b, nullptr, n_head_rows, s.h, s.V, s.V, s.h, s.h, 0, 0, 1,
+    RUN(sd_gemm_bf16_splitk(dlogits, p->lm_head, b.dxb[top], nullptr, n_head_rows, s.h, s.V, s.V, s.h, s.h, 0, 0, 1,
                             b.ws_splitk, b.splitk_bytes, stream));
-    RUN(sd_rows_scatter(b.dx_b, head_rows, b.dxn, n_head_rows, s.M, s.h, stream));
+    RUN(sd_rows_scatter(b.dxb[top], head_rows, b.dxn, n_head_rows, s.M, s.h, stream));
   } else {
     RUN(sd_gemm_bf16(dlogits, xn_f, g->lm_head, ACC(g->lm_head), s.V, s.h, s.M, s.V, s.h, s.h, s.h, 1, 1,
                      (ovl & 1) ? wstream : stream));
@@ -241,51 +250,93 @@ extern "C" int sd_qwen3_backward_rows(const sd_qwen3_dims* d, const sd_qwen3_par
                                           EV, stream));                                                                  \
     else RUN(sd_rmsnorm_bwd2(b.dxn, X, W, RSTD, DRES, DX, DW, acc, WS, s.M, s.h, RS, EV, stream));                         \
   } while (0)
-  NORM_BWD(x_last, p->final_norm, (const float*)rstd_f, nullptr, b.dx_a, g->final_norm, b.ws_norm, nullptr, nullptr);
+  NORM_BWD(x_last, p->final_norm, (const float*)rstd_f, nullptr, b.dxa[top], g->final_norm, b.ws_norm, nullptr, nullptr);
   JOIN();
   if (on_grads_ready) on_grads_ready(SD_STAGE_HEAD, cb_user);
+  // The four weight gradients of a layer run as ONE persistent grouped launch (sd_gemm_grouped_tn: 926 vs 587 TFLOP/s
+  // for four separate launches) on the side stream once the layer's dX chain has produced their inputs, i.e. under
+  // the chain of the NEXT layer; that layer joins it (event) before it overwrites the gradient buffer they share,
+  // and only then is the finished layer reported to the caller.  Gradient accumulation (dW += ...) and
+  // SD_OVERLAP_MASK bit 3 = 0 keep four separate GEMMs launched as their inputs appear.
+  const bool grouped = (ovl & 8) && !acc;
+  int pending = -1;  // layer whose grouped dW is in flight on the side stream
   for (int l = s.L - 1; l >= 0; --l) {
+    const int P = l & 1;
+    char *dx_in = b.dxa[P], *dx_out = (l == 0 && dx0_out) ? (char*)dx0_out : b.dxa[P ^ 1];
+    char *dxb = b.dxb[P], *dqkv = b.dqkv[P], *dgu = b.dgu[P];
     LayerActs a = carve(s, base + (int64_t)l * s.per_layer());
     const sd_qwen3_layer& w = p->layers_host[l];
     const sd_qwen3_layer& gw = g->layers_host[l];
     // MLP
-    SIGNAL(0);  // dx_a final
-    RUN(sd_gemm_bf16(b.dx_a, a.act, gw.wdown, ACC(gw.wdown), s.h, s.I, s.M, s.h, s.I, s.I, s.I, 1, 1, wstream));
-    // d(act) = dx_a . W_down with the SwiGLU backward in the epilogue: d(act) itself never reaches HBM
+    if (!grouped) {
+      SIGNAL(0);  // dx_in final
+      RUN(sd_gemm_bf16(dx_in, a.act, gw.wdown, ACC(gw.wdown), s.h, s.I, s.M, s.h, s.I, s.I, s.I, 1, 1, wstream));
+    }
+    // d(act) = dx_in . W_down with the SwiGLU backward in the epilogue: d(act) itself never reaches HBM
     {
-      const int rc = sd_gemm_swiglu_bwd(b.dx_a, w.wdown, a.gu, b.dgu, s.M, s.I, s.h, stream);
+      const int rc = sd_gemm_swiglu_bwd(dx_in, w.wdown, a.gu, dgu, s.M, s.I, s.h, stream);
       if (rc == SD_ERR_UNSUPPORTED) {
-        RUN(sd_gemm_bf16(b.dx_a, w.wdown, b.dact, nullptr, s.M, s.I, s.h, s.h, s.I, s.I, 0, 0, 1, stream));
-        RUN(sd_swiglu_bwd(b.dact, a.gu, b.dgu, s.M, s.I, stream));
+        RUN(sd_gemm_bf16(dx_in, w.wdown, b.dact, nullptr, s.M, s.I, s.h, s.h, s.I, s.I, 0, 0, 1, stream));
+        RUN(sd_swiglu_bwd(b.dact, a.gu, dgu, s.M, s.I, stream));
       } else if (rc) {
         return rc;
       }
     }
-    SIGNAL(1);  // dgu final
-    RUN(sd_gemm_bf16_splitk_partial(b.dgu, w.wgu, b.dxn, s.M, s.h, 2 * s.I, 2 * s.I, s.h, s.h, 0, 1, b.ws_splitk,
+    if (!grouped) SIGNAL(1);  // dgu final
+    RUN(sd_gemm_bf16_splitk_partial(dgu, w.wgu, b.dxn, s.M, s.h, 2 * s.I, 2 * s.I, s.h, s.h, 0, 1, b.ws_splitk,
                                     b.splitk_bytes, &nsp, stream));
-    RUN(sd_gemm_bf16(b.dgu, a.xn2, gw.wgu, ACC(gw.wgu), 2 * s.I, s.h, s.M, 2 * s.I, s.h, s.h, s.h, 1, 1, wstream));
-    NORM_BWD(a.x_mid, w.ln2, (const float*)a.rstd2, b.dx_a, b.dx_b, gw.ln2, b.ws_norm2, (ovl & 2) ? side_stream : nullptr,
+    if (!grouped) RUN(sd_gemm_bf16(dgu, a.xn2, gw.wgu, ACC(gw.wgu), 2 * s.I, s.h, s.M, 2 * s.I, s.h, s.h, s.h, 1, 1, wstream));
+    NORM_BWD(a.x_mid, w.ln2, (const float*)a.rstd2, dx_in, dxb, gw.ln2, b.ws_norm2[P], (ovl & 2) ? side_stream : nullptr,
              s2 ? (void*)g_ev[8] : nullptr);
-    SIGNAL(2);  // dx_b final
+    if (!grouped) SIGNAL(2);  // dxb final
     // attention
-    RUN(sd_gemm_bf16(b.dx_b, w.wo, b.dao, nullptr, s.M, s.QD, s.h, s.h, s.QD, s.QD, 0, 0, 1, stream));
-    RUN(sd_gemm_bf16(b.dx_b, a.ao, gw.wo, ACC(gw.wo), s.h, s.QD, s.M, s.h, s.QD, s.QD, s.QD, 1, 1, wstream));
+    RUN(sd_gemm_bf16(dxb, w.wo, b.dao, nullptr, s.M, s.QD, s.h, s.h, s.QD, s.QD, 0, 0, 1, stream));
+    if (!grouped) RUN(sd_gemm_bf16(dxb, a.ao, gw.wo, ACC(gw.wo), s.h, s.QD, s.M, s.h, s.QD, s.QD, s.QD, 1, 1, wstream));
     RUN(sd_attn_bwd2(a.qk, a.qk + (int64_t)s.QD * 2, a.qkv + (int64_t)(s.QD + s.KD) * 2, a.ao, b.dao, (const float*)a.lse,
-                    (float*)b.delta, b.dqk, b.dqk + (int64_t)s.QD * 2, b.dqkv + (int64_t)(s.QD + s.KD) * 2, kv_len, s.QK,
+                    (float*)b.delta, b.dqk, b.dqk + (int64_t)s.QD * 2, dqkv + (int64_t)(s.QD + s.KD) * 2, kv_len, s.QK,
                     s.QK, s.QKV, s.QD, s.QK, s.QK, s.QKV, B, T, s.Hq, s.Hkv, 128, scale, (ovl & 4) ? side_stream : nullptr, stream));
-    RUN(sd_qknorm_rope_bwd2(b.dqk, a.qkv, w.q_gain, w.k_gain, cos_tab, sin_tab, b.dqkv, gw.q_gain, gw.k_gain, acc, b.ws_qk,
+    RUN(sd_qknorm_rope_bwd2(b.dqk, a.qkv, w.q_gain, w.k_gain, cos_tab, sin_tab, dqkv, gw.q_gain, gw.k_gain, acc, b.ws_qk[P],
                             s.M, T, s.Hq, s.Hkv, d->eps, (ovl & 2) ? side_stream : nullptr, s2 ? (void*)g_ev[9] : nullptr, stream));
-    SIGNAL(3);  // dqkv final
-    RUN(sd_gemm_bf16(b.dqkv, a.xn1, gw.wqkv, ACC(gw.wqkv), s.QKV, s.h, s.M, s.QKV, s.h, s.h, s.h, 1, 1, wstream));
-    RUN(sd_gemm_bf16_splitk_partial(b.dqkv, w.wqkv, b.dxn, s.M, s.h, s.QKV, s.QKV, s.h, s.h, 0, 1, b.ws_splitk,
+    SIGNAL(3);  // dqkv final (and with it dx_in, dgu, dxb of this layer)
+    if (grouped) {
+      sd_gemm_problem pr[4] = {
+          {dqkv, a.xn1, gw.wqkv, s.QKV, s.h, s.h, s.QKV, s.h},    // dW_qkv  [QKV,h]  = dqkv^T . xn1
+          {dgu, a.xn2, gw.wgu, 2 * s.I, s.h, s.h, 2 * s.I, s.h},  // dW_gu   [2I,h]   = dgu^T  . xn2
+          {dx_in, a.act, gw.wdown, s.h, s.I, s.I, s.h, s.I},      // dW_down [h,I]    = dx_in^T . act
+          {dxb, a.ao, gw.wo, s.h, s.QD, s.QD, s.h, s.QD}};        // dW_o    [h,QD]   = dxb^T  . ao
+      const int rc = sd_gemm_grouped_tn(pr, 4, s.M, wstream);
+      if (rc == SD_ERR_UNSUPPORTED) {
+        for (const sd_gemm_problem& q : pr)
+          RUN(sd_gemm_bf16(q.A, q.B, q.C, nullptr, q.M, q.N, s.M, q.lda, q.ldb, q.ldc, 0, 1, 1, wstream));
+      } else if (rc) {
+        return rc;
+      }
+      if (s2 && hipEventRecord(g_ev[10 + P], s2) != hipSuccess) return SD_ERR_WORKSPACE;
+    } else {
+      RUN(sd_gemm_bf16(dqkv, a.xn1, gw.wqkv, ACC(gw.wqkv), s.QKV, s.h, s.M, s.QKV, s.h, s.h, s.h, 1, 1, wstream));
+    }
+    RUN(sd_gemm_bf16_splitk_partial(dqkv, w.wqkv, b.dxn, s.M, s.h, s.QKV, s.QKV, s.h, s.h, 0, 1, b.ws_splitk,
                                     b.splitk_bytes, &nsp, stream));
-    JOIN();  // the layer's dW GEMMs are done before dx_a / dgu / dx_b / dqkv are overwritten and before the callback
-    NORM_BWD(a.x_in, w.ln1, (const float*)a.rstd1, b.dx_b, (l == 0 && dx0_out) ? dx0_out : b.dx_a, gw.ln1, b.ws_norm,
-             nullptr, nullptr);
-    if (on_grads_ready) on_grads_ready(l, cb_user);
+    if (grouped) {
+      // the previous layer's grouped dW reads the buffer this layer is about to overwrite with its output gradient
+      if (pending >= 0 && s2 && hipStreamWaitEvent(s1, g_ev[10 + (pending & 1)], 0) != hipSuccess) return SD_ERR_WORKSPACE;
+    } else {
+      JOIN();  // the layer's dW GEMMs are done before their inputs are overwritten and before the callback
+    }
+    NORM_BWD(a.x_in, w.ln1, (const float*)a.rstd1, dxb, dx_out, gw.ln1, b.ws_norm, nullptr, nullptr);
+    if (grouped) {
+      if (pending >= 0 && on_grads_ready) on_grads_ready(pending, cb_user);
+      pending = l;
+    } else if (on_grads_ready) {
+      on_grads_ready(l, cb_user);
+    }
   }
-  if (!dx0_out) RUN(sd_embedding_bwd(ids, b.dx_a, g->embed, s.M, s.h, s.V, 1.0f, stream));
+  if (grouped && pending >= 0) {
+    if (s2 && hipStreamWaitEvent(s1, g_ev[10 + (pending & 1)], 0) != hipSuccess) return SD_ERR_WORKSPACE;
+    if (on_grads_ready) on_grads_ready(pending, cb_user);
+  }
+  JOIN();  // everything the side stream was given (gain reduces, dQ) before the call returns
+  if (!dx0_out) RUN(sd_embedding_bwd(ids, b.dxa[1], g->embed, s.M, s.h, s.V, 1.0f, stream));
   if (on_grads_ready) on_grads_ready(SD_STAGE_EMBED, cb_user);
 #undef ACC
 #undef NORM_BWD

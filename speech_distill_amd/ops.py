@@ -239,6 +239,26 @@ class KDLossFn(torch.autograd.Function):
         return grad, None, None, None, None, None, None, None, None
 
 
+def gemm_grouped_tn(pairs):
+    """[(dY [K,M], X [K,N]), ...] (at most 4, common K) -> [dY^T @ X [M,N], ...] in one persistent launch."""
+    import ctypes as C
+    from ._lib import GemmProblem
+    n = len(pairs)
+    probs = (GemmProblem * n)()
+    outs = []
+    K = pairs[0][0].shape[0]
+    for i, (a, b) in enumerate(pairs):
+        _need(a, torch.bfloat16, "dY"), _need(b, torch.bfloat16, "X")
+        if a.shape[0] != K or b.shape[0] != K:
+            raise ValueError("gemm_grouped_tn: every problem must have the same contraction length")
+        c = torch.empty(a.shape[1], b.shape[1], dtype=torch.bfloat16, device=a.device)
+        outs.append(c)
+        probs[i] = GemmProblem(a.data_ptr(), b.data_ptr(), c.data_ptr(), a.stride(0), b.stride(0), c.stride(0), a.shape[1],
+                               b.shape[1])
+    check(load_lib().sd_gemm_grouped_tn(C.cast(probs, C.c_void_p), n, K, _stream()), "sd_gemm_grouped_tn")
+    return outs
+
+
 def gemm_swiglu_bwd(dy, wdown, gate_up):
     """d(gate|up) [M,2I] from dy [M,h], W_down [h,I] (torch layout [out=h, in=I]) and the forward's gate|up."""
     _need(dy, torch.bfloat16, "dy")

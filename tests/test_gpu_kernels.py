@@ -213,6 +213,22 @@ def test_gemm_swiglu_bwd_epilogue_equals_the_separate_kernels(ops, bm, nst):
     assert torch.equal(got, ref), float((got.float() - ref.float()).abs().max())
 
 
+@pytest.mark.parametrize("K", [64, 200, 2048])
+def test_gemm_grouped_tn_equals_separate_gemms(ops, K):
+    """the four weight-gradient GEMMs of a layer as one persistent launch == four sd_gemm_bf16(trans_a, trans_b) calls,
+    bit for bit; ragged M/N, 1..4 problems, fewer and more tiles than CUs; run twice (race screen)."""
+    g = torch.Generator().manual_seed(K)
+    shapes = [(4096, 1000), (1024, 2048), (6152, 1024), (520, 3072)]
+    pairs = [(to_dev(bf(torch.randn(K, m, generator=g))), to_dev(bf(torch.randn(K, n, generator=g)))) for m, n in shapes]
+    ref = [ops.gemm(a, b, True, True) for a, b in pairs]
+    for n in (4, 1, 2):
+        got = ops.gemm_grouped_tn(pairs[:n])
+        again = ops.gemm_grouped_tn(pairs[:n])
+        for i in range(n):
+            assert torch.equal(got[i], ref[i]), (n, i, float((got[i].float() - ref[i].float()).abs().max()))
+            assert torch.equal(got[i], again[i])
+
+
 def test_gemm_split_k(ops):
     """few tiles + long K -> fp32 slabs + fixed-order reduce (the lm_head dX shape class)."""
     g = torch.Generator().manual_seed(6)
