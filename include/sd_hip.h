@@ -60,7 +60,8 @@ int sd_gemm_bf16_splitk_partial(const void* A, const void* B, void* C, int M, in
 int sd_gemm_swiglu(const void* x, const void* wgu, void* gu_out, void* act_out, int M, int I, int K, void* stream);
 /* The four weight-gradient GEMMs of a decoder layer (autograd of HF:252-254, 279, 81-83) as ONE persistent launch:
  * C_p [M_p,N_p] = A_p^T . B_p, p < n <= 4, A_p = dY_p [K,M_p] (row stride lda), B_p = X_p [K,N_p], common K = tokens.
- * Overwrites C_p (no accumulation).  Same results as n calls of sd_gemm_bf16(trans_a=1, trans_b=1). */
+ * accumulate: 0 overwrite C_p, 1 C_p += (gradient accumulation).  Same results as n calls of
+ * sd_gemm_bf16(trans_a=1, trans_b=1[, R = C]). */
 typedef struct {
   const void* A;
   const void* B;
@@ -68,7 +69,7 @@ typedef struct {
   int64_t lda, ldb, ldc;
   int32_t M, N;
 } sd_gemm_problem;
-int sd_gemm_grouped_tn(const sd_gemm_problem* probs, int n, int K, void* stream);
+int sd_gemm_grouped_tn(const sd_gemm_problem* probs, int n, int K, int accumulate, void* stream);
 /* backward twin: d(gate|up) [M,2I] = SwiGLU'(gate_up) applied to d(act) = dy [M,H] . W_down [H,I], in the epilogue of
  * that GEMM (d(act) is never stored); equals sd_gemm_bf16 (NN) + sd_swiglu_bwd bit for bit. */
 int sd_gemm_swiglu_bwd(const void* dy, const void* wdown, const void* gate_up, void* dgate_up, int M, int I, int H,

@@ -80,7 +80,7 @@ PROTOTYPES = {
     "sd_kdloss_stats_bytes": (_i64, [_i, _i]),
     "sd_kdloss_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _i, _vp]),
     "sd_kdloss_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _i, _vp]),
-    "sd_gemm_grouped_tn": (_i, [_vp, _i, _i, _vp]),
+    "sd_gemm_grouped_tn": (_i, [_vp, _i, _i, _i, _vp]),
     "sd_gemm_swiglu_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "sd_kdloss_fwd_rows": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _vp]),
     "sd_kdloss_bwd_rows": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _vp]),

@@ -774,6 +774,7 @@ struct GroupArgs {
   int n;
 };
 
+template <bool ACCUM>
 __global__ __launch_bounds__(768) void gemm_pgroup_tn_kernel(GroupArgs ga, int K, int group_m) {
   constexpr int BM = 256, NW = 8, NPROD = 4, NST = 3, DEPTH = NST - 1;
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;  // 48 KiB
@@ -891,11 +892,19 @@ __global__ __launch_bounds__(768) void gemm_pgroup_tn_kernel(GroupArgs ga, int K
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int gm0 = tm * BM + wm * 64 + i * 16, gn0 = tn * BN + wn * 64;
+        bf16x4 prev[4];
+        if constexpr (ACCUM) {  // C += ...: the old value joins the fp32 sum before the one rounding (as sd_gemm_bf16 with R = C)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int gmr = gm0 + r, gn = gn0 + j * 16 + q4 * 4;
+            prev[j] = (gmr < M && gn < N) ? *(const bf16x4*)(C + (long)gmr * ldc + gn) : bf16x4{};
+          }
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           bf16x4 o;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = (bf16)acc[i][j][e];
+          for (int e = 0; e < 4; ++e) o[e] = (bf16)(ACCUM ? acc[i][j][e] + (float)prev[j][e] : acc[i][j][e]);
           *(bf16x4*)(ep + r * 128 + (((2 * j + (q4 >> 1)) ^ (r & 7)) << 4) + (q4 & 1) * 8) = o;
           acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
@@ -1297,8 +1306,9 @@ extern "C" int sd_gemm_bf16_splitk_partial(const void* A, const void* B, void* C
 }
 
 // Weight gradients of one layer in one persistent launch: C_p [M_p,N_p] = A_p^T . B_p for p < n <= 4, A_p [K,M_p]
-// (row stride lda), B_p [K,N_p], common K.  SD_ERR_UNSUPPORTED when a problem does not fit the descriptor staging.
-extern "C" int sd_gemm_grouped_tn(const sd_gemm_problem* probs, int n, int K, void* stream) {
+// (row stride lda), B_p [K,N_p], common K; accumulate: C_p += ....  SD_ERR_UNSUPPORTED when a problem does not fit the
+// descriptor staging.
+extern "C" int sd_gemm_grouped_tn(const sd_gemm_problem* probs, int n, int K, int accumulate, void* stream) {
   if (n <= 0 || n > 4 || K <= 0 || !probs) return SD_ERR_SHAPE;
   GroupArgs ga{};
   int start = 0;
@@ -1324,7 +1334,12 @@ extern "C" int sd_gemm_grouped_tn(const sd_gemm_problem* probs, int n, int K, vo
   cus &= ~7;
   if (cus <= 0) return SD_ERR_UNSUPPORTED;
   SdProfScope prof(SD_K_GEMM_TN, flops, (hipStream_t)stream);
-  hipLaunchKernelGGL(gemm_pgroup_tn_kernel, dim3(start < cus ? start : cus), dim3(768), 0, (hipStream_t)stream, ga, K, 4);
+  if (accumulate)
+    hipLaunchKernelGGL(gemm_pgroup_tn_kernel<true>, dim3(start < cus ? start : cus), dim3(768), 0, (hipStream_t)stream, ga,
+                       K, 4);
+  else
+    hipLaunchKernelGGL(gemm_pgroup_tn_kernel<false>, dim3(start < cus ? start : cus), dim3(768), 0, (hipStream_t)stream, ga,
+                       K, 4);
   SD_CHECK_LAUNCH();
   return 0;
 }

@@ -256,9 +256,9 @@ extern "C" int sd_qwen3_backward_rows(const sd_qwen3_dims* d, const sd_qwen3_par
   // The four weight gradients of a layer run as ONE persistent grouped launch (sd_gemm_grouped_tn: 926 vs 587 TFLOP/s
   // for four separate launches) on the side stream once the layer's dX chain has produced their inputs, i.e. under
   // the chain of the NEXT layer; that layer joins it (event) before it overwrites the gradient buffer they share,
-  // and only then is the finished layer reported to the caller.  Gradient accumulation (dW += ...) and
-  // SD_OVERLAP_MASK bit 3 = 0 keep four separate GEMMs launched as their inputs appear.
-  const bool grouped = (ovl & 8) && !acc;
+  // and only then is the finished layer reported to the caller.  SD_OVERLAP_MASK bit 3 = 0 keeps four separate GEMMs
+  // launched as their inputs appear.
+  const bool grouped = (ovl & 8) != 0;
   int pending = -1;  // layer whose grouped dW is in flight on the side stream
   for (int l = s.L - 1; l >= 0; --l) {
     const int P = l & 1;
@@ -304,10 +304,10 @@ extern "C" int sd_qwen3_backward_rows(const sd_qwen3_dims* d, const sd_qwen3_par
           {dgu, a.xn2, gw.wgu, 2 * s.I, s.h, s.h, 2 * s.I, s.h},  // dW_gu   [2I,h]   = dgu^T  . xn2
           {dx_in, a.act, gw.wdown, s.h, s.I, s.I, s.h, s.I},      // dW_down [h,I]    = dx_in^T . act
           {dxb, a.ao, gw.wo, s.h, s.QD, s.QD, s.h, s.QD}};        // dW_o    [h,QD]   = dxb^T  . ao
-      const int rc = sd_gemm_grouped_tn(pr, 4, s.M, wstream);
+      const int rc = sd_gemm_grouped_tn(pr, 4, s.M, acc, wstream);
       if (rc == SD_ERR_UNSUPPORTED) {
         for (const sd_gemm_problem& q : pr)
-          RUN(sd_gemm_bf16(q.A, q.B, q.C, nullptr, q.M, q.N, s.M, q.lda, q.ldb, q.ldc, 0, 1, 1, wstream));
+          RUN(sd_gemm_bf16(q.A, q.B, q.C, acc ? q.C : nullptr, q.M, q.N, s.M, q.lda, q.ldb, q.ldc, q.ldc, 1, 1, wstream));
       } else if (rc) {
         return rc;
       }

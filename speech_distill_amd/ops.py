@@ -239,8 +239,9 @@ class KDLossFn(torch.autograd.Function):
         return grad, None, None, None, None, None, None, None, None
 
 
-def gemm_grouped_tn(pairs):
-    """[(dY [K,M], X [K,N]), ...] (at most 4, common K) -> [dY^T @ X [M,N], ...] in one persistent launch."""
+def gemm_grouped_tn(pairs, accumulate_into=None):
+    """[(dY [K,M], X [K,N]), ...] (at most 4, common K) -> [dY^T @ X [M,N], ...] in one persistent launch;
+    accumulate_into: list of [M,N] tensors to add to in place."""
     import ctypes as C
     from ._lib import GemmProblem
     n = len(pairs)
@@ -251,11 +252,13 @@ def gemm_grouped_tn(pairs):
         _need(a, torch.bfloat16, "dY"), _need(b, torch.bfloat16, "X")
         if a.shape[0] != K or b.shape[0] != K:
             raise ValueError("gemm_grouped_tn: every problem must have the same contraction length")
-        c = torch.empty(a.shape[1], b.shape[1], dtype=torch.bfloat16, device=a.device)
+        c = (torch.empty(a.shape[1], b.shape[1], dtype=torch.bfloat16, device=a.device) if accumulate_into is None
+             else accumulate_into[i])
         outs.append(c)
         probs[i] = GemmProblem(a.data_ptr(), b.data_ptr(), c.data_ptr(), a.stride(0), b.stride(0), c.stride(0), a.shape[1],
                                b.shape[1])
-    check(load_lib().sd_gemm_grouped_tn(C.cast(probs, C.c_void_p), n, K, _stream()), "sd_gemm_grouped_tn")
+    check(load_lib().sd_gemm_grouped_tn(C.cast(probs, C.c_void_p), n, K, int(accumulate_into is not None), _stream()),
+          "sd_gemm_grouped_tn")
     return outs
 
 

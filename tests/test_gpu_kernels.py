@@ -227,6 +227,13 @@ def test_gemm_grouped_tn_equals_separate_gemms(ops, K):
         for i in range(n):
             assert torch.equal(got[i], ref[i]), (n, i, float((got[i].float() - ref[i].float()).abs().max()))
             assert torch.equal(got[i], again[i])
+    # accumulate: C += A^T B, the old value joins the fp32 sum before the one rounding (== sd_gemm_bf16 with R = C)
+    base = [to_dev(bf(torch.randn(m, n, generator=g) * 4)) for m, n in shapes]
+    want = [ops.gemm(a, b, True, True, residual=c0) for (a, b), c0 in zip(pairs, base)]
+    acc = [c0.clone() for c0 in base]
+    ops.gemm_grouped_tn(pairs, accumulate_into=acc)
+    for i in range(4):
+        assert torch.equal(acc[i], want[i]), (i, float((acc[i].float() - want[i].float()).abs().max()))
 
 
 def test_gemm_split_k(ops):
