@@ -9,6 +9,7 @@
 //   SwiGLU ......... modeling_qwen3.py:81-83
 //   embedding ...... modeling_qwen3.py:381
 // Every kernel moves 16 bytes per lane per access (8 bf16) and reduces with wave shuffles.
+#include <stdlib.h>
 #include "sd_common.cuh"
 #include "../../include/sd_hip.h"
 #include "sd_prof.h"
@@ -481,7 +482,8 @@ extern "C" int sd_qknorm_rope_fwd(const void* qkv, const void* q_gain, const voi
 }
 
 static inline int qk_bwd_blocks(long items, int* ipb) {
-  long per = (items + 511) / 512;
+  static const long nblk = getenv("SD_QK_BWD_BLOCKS") ? atol(getenv("SD_QK_BWD_BLOCKS")) : 512;  // A/B measurements
+  long per = (items + nblk - 1) / nblk;
   per = (per + 47) / 48 * 48;  // a whole number of 16-lane-group trips of 3 items (qknorm_rope_bwd_kernel)
   *ipb = (int)per;
   return (int)((items + per - 1) / per);
