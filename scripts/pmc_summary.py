@@ -21,7 +21,34 @@ def per_kernel(path, counter):
     return acc
 
 
+def mfma_busy(src, dst, n_cu=256):
+    """MFMA-busy share of each kernel's active time: SQ_VALU_MFMA_BUSY_CYCLES (cycles summed over the 4 SIMDs of every
+    CU) / (active cycles x CUs x 4) -- the gfx94x MfmaUtil formula (ROCm 7.2 has no gfx950 derived counters).
+    rocprofv3 reports GRBM_GUI_ACTIVE summed over the 8 XCDs, so active cycles = GRBM_GUI_ACTIVE / 8 (checked against
+    the event-timed TFLOP/s of the GEMM kernels: 0.48 busy for the kernel that runs at 1 145 of 2 500 TFLOP/s)."""
+    busy = per_kernel(src + "/mfma", "SQ_VALU_MFMA_BUSY_CYCLES")
+    act = per_kernel(src + "/mfma", "GRBM_GUI_ACTIVE")
+    rows = []
+    tb = ta = 0.0
+    for k, (n, b) in busy.items():
+        a = act.get(k, [0, 0.0])[1]
+        if a <= 0:
+            continue
+        tb += b
+        ta += a
+        if b > 0:
+            rows.append({"kernel": k[:160], "launches": n, "gui_active_cycles": a, "mfma_busy_share": b / (a / 8.0 * n_cu * 4)})
+    rows.sort(key=lambda r: -r["gui_active_cycles"])
+    out = {"method": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE over `python3 bench.py --steps 2 --warmup 1 "
+                     "--no-cpu-baseline --no-prof --no-overlap`; share = busy / (GRBM_GUI_ACTIVE / 8 XCDs * 256 CUs * 4 SIMDs)",
+           "whole_run_mfma_busy_share": tb / (ta / 8.0 * n_cu * 4) if ta else None, "kernels": rows[:40]}
+    json.dump(out, open(dst, "w"), indent=1)
+    print(json.dumps({"whole_run": out["whole_run_mfma_busy_share"], "top": [(r["kernel"][:70], round(r["mfma_busy_share"], 3)) for r in rows[:12]]}, indent=1))
+
+
 def main():
+    if len(sys.argv) > 3 and sys.argv[3] == "mfma":
+        return mfma_busy(sys.argv[1], sys.argv[2])
     src, dst = sys.argv[1], sys.argv[2]
     fetch = per_kernel(src + "/fetch", "FETCH_SIZE")
     write = per_kernel(src + "/write", "WRITE_SIZE")
