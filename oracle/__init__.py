@@ -5,7 +5,7 @@ hot-path arithmetic.  It exists so that the hand-written HIP kernels in
 ``speech_distill_amd`` have something independent to be checked against on the
 GPU box, where ``/root/reference`` does not exist.
 
-Rules (enforced by ``tests/test_no_oracle_in_product.py``):
+Rules (enforced by ``tests/test_cabi.py::test_product_never_imports_the_oracle``):
   * only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of
     ``bench.py`` may import anything from here;
   * nothing in ``speech_distill_amd/`` imports it, and the product path raises
