@@ -52,8 +52,20 @@ def synthetic_batch(B, T, rank, device):
             "teacher_attention_mask": torch.ones(B, T, dtype=torch.long, device=device)}
 
 
+def cpu_model_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(sample_T, threads, n_seq=2):
-    """Oracle (port of the reference CPU path) on host cores: full-shape models, n_seq sequences."""
+    """Oracle (port of the reference CPU path) on host cores: full-shape models, n_seq sequences.
+    Weights are rounded to bf16 first (the values the HIP path holds) and returned with the batch, so that the GPU
+    path can be run on the identical sample afterwards (`loss_match`)."""
     from oracle import qwen3 as Q
     from oracle import step as S
     torch.set_num_threads(threads)
@@ -63,7 +75,8 @@ def cpu_baseline(sample_T, threads, n_seq=2):
     for shape, dst, seed in ((Q.STUDENT_06B, sw, 0), (Q.TEACHER_17B, tw, 1)):
         gg = torch.Generator().manual_seed(seed)
         for name, shp in Q.param_names(shape):
-            dst[name] = torch.ones(shp) if len(shp) == 1 else torch.empty(shp).normal_(0, 0.02, generator=gg)
+            dst[name] = (torch.ones(shp) if len(shp) == 1 else
+                         torch.empty(shp).normal_(0, 0.02, generator=gg).bfloat16().float())
     ids = torch.randint(0, VOCAB, (n_seq, sample_T), generator=g)
     ids[:, sample_T // 4:] = torch.randint(SPEECH_LO, VOCAB, (n_seq, sample_T - sample_T // 4), generator=g)
     labels = ids.clone()
@@ -72,10 +85,11 @@ def cpu_baseline(sample_T, threads, n_seq=2):
     t0 = time.time()
     out = S.distill_step(sw, Q.STUDENT_06B, tw, Q.TEACHER_17B, batch, 2.0, 0.5, top_k=128, acc=torch.float32)
     dt = time.time() - t0
-    return {"value": n_seq * sample_T / dt, "unit": "tokens/s", "cores": threads, "kind": "port",
-            "sample": f"{n_seq} sequences x {sample_T} tokens (of the 4 x 512 batch), full-shape teacher+student, fp32, "
-                      f"one micro-step incl. backward, {dt:.1f} s",
-            "loss": float(out["total"])}
+    res = {"value": n_seq * sample_T / dt, "unit": "tokens/s", "cores": threads, "cpu": cpu_model_name(), "kind": "port",
+           "sample": f"{n_seq} sequences x {sample_T} tokens (of the 4 x 512 batch), full-shape teacher+student, fp32 "
+                     f"arithmetic on bf16-rounded weights, one micro-step incl. backward, {dt:.1f} s",
+           "loss": float(out["total"])}
+    return res, sw, tw, batch, out
 
 
 def main():
@@ -151,11 +165,10 @@ def main():
 
     phase_ev = []
 
-    def mark():
-        if args.phases:
-            e = torch.cuda.Event(enable_timing=True)
-            e.record()
-            phase_ev.append(e)
+    def mark():  # 5 event records per step on the current stream (always on: the backward time feeds the JSON line)
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        phase_ev.append(e)
 
     def step(overlap=True):
         # the same sequence as speech_distill_amd.trainer.DistillationTrainer.compute_loss on a training step
@@ -194,28 +207,28 @@ def main():
     for _ in range(args.warmup):
         out = step()
     barrier()
+    phase_ev.clear()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
     barrier()
     dt = time.perf_counter() - t0
+    n_ph = 5
+    names = ["student_fwd_teacher_beside", "wait_teacher_topk", "loss_fwd", "backward"]
+    phase_ms = [0.0] * 4
+    for k in range(0, len(phase_ev) - n_ph + 1, n_ph):
+        for j in range(4):
+            phase_ms[j] += phase_ev[k + j].elapsed_time(phase_ev[k + j + 1]) / max(1, len(phase_ev) // n_ph)
+    phase_ev.clear()
     if args.phases and rank == 0:
-        import sys
         torch.cuda.synchronize()
         t_enq = time.perf_counter()
         step()
         t_enq = time.perf_counter() - t_enq
         torch.cuda.synchronize()
         print(f"[phase] host time to enqueue one step (GPU idle at start): {t_enq * 1e3:.3f} ms", file=sys.stderr)
-        n = 5
-        ev = phase_ev[-n * args.steps:] if len(phase_ev) >= n * args.steps else phase_ev
-        names = ["student fwd (teacher beside it)", "wait for teacher + top-K", "loss fwd", "backward"]
-        acc = [0.0] * 4
-        for k in range(0, len(ev) - n + 1, n):
-            for j in range(4):
-                acc[j] += ev[k + j].elapsed_time(ev[k + j + 1])
         for j in range(4):
-            print(f"[phase] {names[j]:34s} {acc[j] / max(1, len(ev) // n):7.3f} ms", file=sys.stderr)
+            print(f"[phase] {names[j]:34s} {phase_ms[j]:7.3f} ms", file=sys.stderr)
     # Per-kernel durations: the SAME K steps again, immediately after the timed region, with HIP events
     # recorded on the launch stream around every launch.  Kept out of the timed region because ~2 000
     # event records per step stretch the step by ~20 % (measured 39.8 vs 32.9 ms) and would understate `value`.
@@ -249,7 +262,12 @@ def main():
     if rank == 0:
         tokens = world * args.batch * args.seq_len * args.steps
         from oracle.qwen3 import STUDENT_06B, TEACHER_17B, flops_per_token
-        f_tok = 3 * flops_per_token(STUDENT_06B, args.seq_len) + flops_per_token(TEACHER_17B, args.seq_len)
+        f_student = flops_per_token(STUDENT_06B, args.seq_len)
+        f_tok = 3 * f_student + flops_per_token(TEACHER_17B, args.seq_len)
+        n_rows = args.batch * args.seq_len if args.full_head else int(ops.loss_rows(batch["labels"])[0].numel())
+        skipped_rows = args.batch * args.seq_len - n_rows
+        head_s, head_t = 2.0 * STUDENT_06B.hidden_size * VOCAB, 2.0 * TEACHER_17B.hidden_size * VOCAB  # lm_head FLOPs per row
+        step_flops_exec = f_tok * args.batch * args.seq_len - skipped_rows * (3 * head_s + head_t)
         res = {
             "metric": "distill-step tokens/sec (student seq_len=512)", "value": tokens / dt, "unit": "tokens/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
@@ -260,7 +278,17 @@ def main():
                        "global_batch": world * args.batch, "seq_len": args.seq_len,
                        "parallelism": f"dp{world}" if world > 1 else "single"},
             "step_flops_per_token_algorithmic": f_tok,
+            # nominal: the reference's work (lm_head on all B*T rows of both models, train.py:54-55) per wall second
             "step_mfma_frac": (tokens / dt) * f_tok / world / (MFMA_PEAK_TFLOPS * 1e12),
+            # executed: what the timed step really computes -- both lm_heads, top-K and loss on the loss rows only
+            "step_mfma_frac_executed": (step_flops_exec / (dt / args.steps)) / (MFMA_PEAK_TFLOPS * 1e12),
+            "head_rows": {"computed": n_rows, "of": args.batch * args.seq_len},
+            "phases_ms": dict(zip(names, phase_ms)),
+            # north-star target (>= 0.40): student backward = 2 x student forward FLOPs over the wall time of the
+            # backward phase (loss backward kernel included); "executed" counts the head on the loss rows only
+            "student_bwd_mfma_frac": 2 * f_student * args.batch * args.seq_len / (phase_ms[3] * 1e-3) / (MFMA_PEAK_TFLOPS * 1e12),
+            "student_bwd_mfma_frac_executed": (2 * f_student * args.batch * args.seq_len - 2 * skipped_rows * head_s)
+                                              / (phase_ms[3] * 1e-3) / (MFMA_PEAK_TFLOPS * 1e12),
             "grad_sync_ok": grad_sync_ok,
             "loss": {"total": losses[0], "task": losses[1], "distill": losses[2], "teacher": losses[3]},
         }
@@ -293,16 +321,37 @@ def main():
         if "roofline" in res and os.path.exists(pmc):
             try:  # HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
                 t = json.load(open(pmc))
-                e = t.get(dom, t["nt_gemm"])
-                res["roofline"]["traffic"] = e["hbm_bytes_per_launch"]
-                res["roofline"]["traffic_source"] = "profiles/r01_pmc_traffic.json (" + e["kernel"] + "): " + t["method"]
+                e = t.get(dom)
+                if e is not None:
+                    res["roofline"]["traffic"] = e["hbm_bytes_per_launch"]
+                    res["roofline"]["traffic_source"] = os.path.relpath(pmc, ROOT) + " (" + e["kernel"] + "): " + t["method"]
             except Exception:
                 pass
         if world == 1 and not args.no_cpu_baseline:
             try:
-                res["cpu_baseline"] = cpu_baseline(args.cpu_sample_tokens, min(os.cpu_count() or 1, 16))
+                cb, sw, tw, cbatch, cout = cpu_baseline(args.cpu_sample_tokens, min(os.cpu_count() or 1, 16))
+                res["cpu_baseline"] = cb
+                # loss match on IDENTICAL inputs: the HIP path on the very sample (weights, ids) the oracle just ran
+                student.load_hf_state_dict(sw)
+                teacher.load_hf_state_dict(tw)
+                del sw, tw
+                gb = {k: v.to(dev) for k, v in cbatch.items()}
+                student.zero_grad()
+                rows, row_labels = ops.loss_rows(gb["labels"])
+                with torch.no_grad():
+                    tv, ti = ops.logsoftmax_topk(teacher(input_ids=gb["input_ids"], attention_mask=gb["attention_mask"],
+                                                         logit_rows=rows).logits, args.top_k, VOCAB)
+                got = loss_fn.forward_rows(student(input_ids=gb["input_ids"], attention_mask=gb["attention_mask"],
+                                                   logit_rows=rows).logits, row_labels, teacher_top_k_v=tv,
+                                           teacher_top_k_i=ti)
+                g4 = [float(x) for x in got]
+                w4 = [float(cout[k]) for k in ("total", "task", "distill", "teacher")]
+                res["loss_match"] = {"hip_bf16": g4, "oracle_fp32": w4, "rel_err_total": abs(g4[0] - w4[0]) / abs(w4[0]),
+                                     "tolerance": 2e-2, "sample": "the cpu_baseline sample: same weights (bf16-rounded), same "
+                                     "ids, full-shape teacher + student", "ok": abs(g4[0] - w4[0]) <= 2e-2 * abs(w4[0])}
             except Exception as e:  # never lose the GPU line to a host-side problem
-                res["cpu_baseline"] = {"value": None, "error": repr(e)}
+                res.setdefault("cpu_baseline", {"value": None, "error": repr(e)})
+                res["loss_match"] = {"error": repr(e)}
         print(json.dumps(res), flush=True)
     if multi:
         dist.barrier()

@@ -38,6 +38,14 @@ def parse_args():
     p.add_argument("--tiny", action="store_true", help="(+) BASELINE config-1-sized models (plumbing runs)")
     p.add_argument("--synthetic_samples", type=int, default=0, help="(+) generate N synthetic pre-processed samples")
     p.add_argument("--max_steps", type=int, default=-1)
+    p.add_argument("--eval_samples", type=int, default=10, help="(+) held-out samples (train.py:262-269 splits off 10)")
+    p.add_argument("--save_strategy", default="epoch", help="(+) train.py:341 hard-codes \"epoch\" (with eval per epoch, "
+                   "load_best_model_at_end, save_total_limit=3); \"no\" turns checkpoints and evaluation off")
+    p.add_argument("--ddp_backend", default=None, help="(+) torch.distributed backend (default: nccl = RCCL on ROCm)")
+    p.add_argument("--equal_length", action="store_true", help="(+) synthetic samples all max_length long (equal N per rank)")
+    p.add_argument("--seed", type=int, default=42)
+    p.add_argument("--log_json", default=None, help="(+) write trainer.state.log_history there (rank 0; every rank if the "
+                   "path contains {rank})")
     return p.parse_args()
 
 
@@ -58,18 +66,9 @@ def build_models(cfg, dev):
         sd, td = ((sda.Qwen3Dims(640, 128, 256, 2, 2, 1), sda.Qwen3Dims(640, 256, 512, 2, 4, 2)) if cfg.tiny else
                   (sda.Qwen3Dims.student_06b(), sda.Qwen3Dims.teacher_17b()))
         return sda.HipQwen3ForCausalLM(sd, device=dev, seed=0), sda.HipQwen3ForCausalLM(td, device=dev, seed=1)
-    from transformers import AutoModelForCausalLM
     out = []
-    for path in (cfg.student_model, cfg.teacher_model):
-        hf = AutoModelForCausalLM.from_pretrained(path, torch_dtype=torch.bfloat16)  # train.py:155-178, CPU load
-        c = hf.config
-        m = sda.HipQwen3ForCausalLM(
-            sda.Qwen3Dims(c.vocab_size, c.hidden_size, c.intermediate_size, c.num_hidden_layers, c.num_attention_heads,
-                          c.num_key_value_heads, getattr(c, "head_dim", 128), c.rms_norm_eps,
-                          getattr(c, "rope_theta", 1e6), c.tie_word_embeddings), device=dev, config=c, init_std=0)
-        m.load_hf_state_dict(hf.state_dict())
-        out.append(m)
-        del hf
+    for path in (cfg.student_model, cfg.teacher_model):     # train.py:155-178 (local HF checkpoint directories)
+        out.append(sda.HipQwen3ForCausalLM.from_pretrained(path, device=dev))
     return out[0], out[1]
 
 
@@ -77,7 +76,6 @@ def main():
     cfg = parse_args()
     from transformers import TrainingArguments
     import speech_distill_amd as sda
-    from speech_distill_amd import ddp
     from speech_distill_amd.collator import ProcessedDataCollator
     from speech_distill_amd.trainer import DistillationTrainer
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
@@ -87,38 +85,54 @@ def main():
     teacher.eval().requires_grad_(False)               # train.py:165-169
     student.gradient_checkpointing_enable()            # train.py:204-208 (accepted; activations are kept in HBM)
     V = student.dims.vocab_size
-    bos = cfg.speech_bos_id if cfg.speech_bos_id is not None else min(152927, V - 2)
+    bos = cfg.speech_bos_id if cfg.speech_bos_id is not None else (152927 if V > 152928 else V // 2)
     pad = cfg.pad_token_id if cfg.pad_token_id < V else V - 1
     if cfg.synthetic_samples:
-        g = torch.Generator().manual_seed(1234 + int(os.environ.get("RANK", 0)))
+        g = torch.Generator().manual_seed(1234)        # the same dataset on every rank; the sampler shards it
         rows = []
         for _ in range(cfg.synthetic_samples):
-            n = int(torch.randint(cfg.max_length // 2, cfg.max_length + 1, (1,), generator=g))
+            n = cfg.max_length if cfg.equal_length else int(torch.randint(cfg.max_length // 2, cfg.max_length + 1, (1,), generator=g))
             nt = max(2, n // 4)
             ids = torch.cat([torch.randint(0, min(bos, V), (nt,), generator=g), torch.tensor([bos]),
                              torch.randint(bos + 1, V, (n - nt - 2,), generator=g), torch.tensor([pad])])
             ids[nt + 1:-1][ids[nt + 1:-1] == pad] = bos + 1
             rows.append({"student_input_ids": ids.tolist(), "student_attention_mask": [1] * n,
                          "teacher_input_ids": ids.tolist(), "teacher_attention_mask": [1] * n})
-        dataset = rows
+        n_eval = min(cfg.eval_samples, max(0, len(rows) // 5)) if cfg.save_strategy != "no" else 0
+        dataset, eval_dataset = rows[:len(rows) - n_eval], (rows[len(rows) - n_eval:] if n_eval else None)
     else:
         from datasets import load_from_disk
         dataset = load_from_disk(cfg.dataset_path)     # train.py:234-236 (pre-processed columns, data.py:124-141)
+        eval_dataset = None
+        if cfg.save_strategy != "no":                  # train.py:262-269
+            split = dataset.train_test_split(test_size=min(cfg.eval_samples, max(1, len(dataset) // 5)), seed=42)
+            dataset, eval_dataset = split["train"], split["test"]
+    evaluate = eval_dataset is not None
     args = TrainingArguments(
         output_dir=cfg.output_dir, per_device_train_batch_size=cfg.per_device_train_batch_size,
         gradient_accumulation_steps=cfg.gradient_accumulation_steps, num_train_epochs=cfg.epochs,
-        learning_rate=cfg.learning_rate, logging_steps=cfg.logging_steps, bf16=True, save_strategy="no",
-        eval_strategy="no", report_to=[], remove_unused_columns=False, label_names=["labels"], max_steps=cfg.max_steps,
-        dataloader_num_workers=0)                      # train.py:331-354
-    trainer = DistillationTrainer(model=student, args=args, train_dataset=dataset,
+        learning_rate=cfg.learning_rate, logging_steps=cfg.logging_steps, bf16=True, gradient_checkpointing=True,
+        eval_strategy="epoch" if evaluate else "no", save_strategy=cfg.save_strategy,
+        load_best_model_at_end=evaluate and cfg.save_strategy == "epoch", save_total_limit=3, report_to=[],
+        remove_unused_columns=False, label_names=["labels"], max_steps=cfg.max_steps, dataloader_num_workers=0,
+        seed=cfg.seed, **({"ddp_backend": cfg.ddp_backend} if cfg.ddp_backend else {}))     # train.py:331-354
+    # Under torchrun the trainer wraps the student in ddp.HipDataParallel itself (DistillationTrainer._wrap_model):
+    # bucketed RCCL all-reduce of the flat gradient under the backward, no_sync on accumulation micro-batches.
+    trainer = DistillationTrainer(model=student, args=args, train_dataset=dataset, eval_dataset=eval_dataset,
                                   data_collator=ProcessedDataCollator(_BosTok(pad, bos), pad_token_id=pad),
                                   teacher_model=teacher, temperature=cfg.temperature, alpha=cfg.alpha, top_k=cfg.top_k)
-    if int(os.environ.get("WORLD_SIZE", 1)) > 1:
-        ddp.attach(student)
     t0 = time.time()
     trainer.train()                                    # train.py:420
     if trainer.is_world_process_zero():
         print(f"done in {time.time() - t0:.1f}s; log tail: {trainer.state.log_history[-3:]}")
+    if cfg.log_json and (trainer.is_world_process_zero() or "{rank}" in cfg.log_json):
+        import json
+        red = getattr(student, "_reducer", None)
+        with open(cfg.log_json.replace("{rank}", os.environ.get("RANK", "0")), "w") as f:
+            json.dump({"log_history": trainer.state.log_history, "best_model_checkpoint": trainer.state.best_model_checkpoint,
+                       "world_size": int(os.environ.get("WORLD_SIZE", 1)), "wrapped": type(trainer.model_wrapped).__name__,
+                       "reducer": None if red is None else red.stats, "global_step": trainer.state.global_step,
+                       "param_checksum": float(student.flat.double().sum())}, f)
 
 
 if __name__ == "__main__":

@@ -6,6 +6,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <mutex>
+#include <vector>
 #include "../../include/sd_hip.h"
 
 namespace {
@@ -82,16 +84,51 @@ struct BwdScratch {
 
 #define RUN(call) do { int e__ = (call); if (e__) return e__; } while (0)
 
-// Events ordering the optional side stream against the main one (created once, timing disabled).
-hipEvent_t g_ev[12];
-bool g_ev_ready = false;
-bool ensure_events() {
-  if (g_ev_ready) return true;
-  for (auto& e : g_ev)
-    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return false;
-  g_ev_ready = true;
-  return true;
+// Events ordering the optional side stream against the main one (timing disabled).  A backward call leases one set
+// for its duration from a small per-device pool: two models running backward at the same time (different host
+// threads) or on different devices never share an event, and nothing is created on the steady-state path.  An event
+// may be re-recorded by a later call while a wait enqueued by an earlier one is still pending: hipStreamWaitEvent
+// captures the record that was current when it was issued.
+constexpr int kNumEvents = 12;
+struct EventSet {
+  hipEvent_t ev[kNumEvents];
+  int device;
+};
+std::mutex g_ev_mu;
+std::vector<EventSet*> g_ev_free;
+
+EventSet* lease_events() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g_ev_mu);
+    for (size_t i = 0; i < g_ev_free.size(); ++i)
+      if (g_ev_free[i]->device == dev) {
+        EventSet* s = g_ev_free[i];
+        g_ev_free.erase(g_ev_free.begin() + i);
+        return s;
+      }
+  }
+  EventSet* s = new EventSet;
+  s->device = dev;
+  for (int i = 0; i < kNumEvents; ++i)
+    if (hipEventCreateWithFlags(&s->ev[i], hipEventDisableTiming) != hipSuccess) {
+      for (int j = 0; j < i; ++j) (void)hipEventDestroy(s->ev[j]);
+      delete s;
+      return nullptr;
+    }
+  return s;
 }
+
+struct EventLease {
+  EventSet* set = nullptr;
+  ~EventLease() {
+    if (set) {
+      std::lock_guard<std::mutex> lk(g_ev_mu);
+      g_ev_free.push_back(set);
+    }
+  }
+};
 
 }  // namespace
 
@@ -218,7 +255,9 @@ extern "C" int sd_qwen3_backward_rows(const sd_qwen3_dims* d, const sd_qwen3_par
   // A/B switch for measurements: SD_OVERLAP_MASK bit0 lm_head dW, bit1 gain reduces, bit2 attention dQ, bit3 grouped per-layer dW (default all on)
   static const int ovl = getenv("SD_OVERLAP_MASK") ? atoi(getenv("SD_OVERLAP_MASK")) : 15;
   hipStream_t s1 = (hipStream_t)stream, s2 = (hipStream_t)side_stream;
-  if (s2 && !ensure_events()) return SD_ERR_WORKSPACE;
+  EventLease lease;
+  if (s2 && !(lease.set = lease_events())) return SD_ERR_WORKSPACE;
+  hipEvent_t* g_ev = lease.set ? lease.set->ev : nullptr;  // this call's events
   void* wstream = s2 ? side_stream : stream;  // where weight-gradient GEMMs go
   // main -> side: "this buffer is final"; side -> main: "this layer's dW GEMMs have read their inputs"
 #define SIGNAL(i) do { if (s2) { if (hipEventRecord(g_ev[i], s1) != hipSuccess || hipStreamWaitEvent(s2, g_ev[i], 0) != hipSuccess) return SD_ERR_WORKSPACE; } } while (0)

@@ -64,6 +64,7 @@ class FlatGradAllReduce:
         self.comm = comm_stream if comm_stream is not None else (torch.cuda.Stream() if self.cuda else None)
         self._works = []
         self.issued = []  # (stage, start, end) actually reduced in the current step (for tests / stats)
+        self.stats = {"backwards": 0, "synced": 0}  # backward passes seen / of which communicated
 
     @contextlib.contextmanager
     def no_sync(self):
@@ -77,27 +78,49 @@ class FlatGradAllReduce:
     def begin_step(self):
         self._works, self.issued = [], []
         self._emb = None
+        self.stats["backwards"] += 1
+        self.stats["synced"] += int(self.sync and self.world > 1)
 
     def wants_split_embedding(self):
         return self.split_embedding and self.sync and self.world > 1
 
     def set_embedding_exchange(self, ids, dx0, embed_grad):
         """Called by the model before backward: token ids [M], buffer that will receive d loss / d embedding
-        output [M,h], and the [V,h] gradient view the rows are scattered into."""
+        output [M,h], and the [V,h] gradient view the rows are scattered into.
+
+        Ranks may hold different M = B*T (the collator pads to the per-batch maximum, data.py:280-327), so the row
+        counts are exchanged here -- on the idle communication stream, before the backward kernels are enqueued, so the
+        host read does not wait for compute -- and ``_exchange_embedding_rows`` pads every rank to the largest."""
         self._emb = (ids, dx0, embed_grad)
+        m_local = ids.numel()
+        ctx = torch.cuda.stream(self.comm) if self.cuda else contextlib.nullcontext()
+        with ctx:
+            mine = torch.tensor([m_local], dtype=torch.int64, device=ids.device)
+            counts = [torch.zeros_like(mine) for _ in range(self.world)]
+            dist.all_gather(counts, mine, group=self.group)
+            self._counts = [int(c) for c in torch.cat(counts).tolist()]
 
     def _exchange_embedding_rows(self):
         """All-gather (ids, rows) of every rank, then the same deterministic scatter-add on every rank:
-        dE += (1/W) sum_r scatter(ids_r, rows_r).  Runs after the dense part's all-reduce (same stream)."""
-        from . import ops
+        dE += (1/W) sum_r scatter(ids_r, rows_r).  Runs after the dense part's all-reduce (same stream).
+        Rows beyond a rank's own count are padding (zeros) and are not scattered."""
         ids, dx0, embed_grad = self._emb
-        W = self.world
+        W, counts = self.world, self._counts
+        m_local, m_max = ids.numel(), max(counts)
+        if m_local < m_max:
+            ids = torch.cat([ids, ids.new_zeros(m_max - m_local)])
+            dx0 = torch.cat([dx0, dx0.new_zeros(m_max - m_local, dx0.shape[1])])
         all_ids = [torch.empty_like(ids) for _ in range(W)]
         all_rows = [torch.empty_like(dx0) for _ in range(W)]
-        dist.all_gather(all_ids, ids, group=self.group)
-        dist.all_gather(all_rows, dx0, group=self.group)
+        dist.all_gather(all_ids, ids.contiguous(), group=self.group)
+        dist.all_gather(all_rows, dx0.contiguous(), group=self.group)
         for r in range(W):
-            ops.embedding_bwd(all_ids[r], all_rows[r], embed_grad, scale=1.0 / W)
+            self._scatter_rows(all_ids[r][:counts[r]], all_rows[r][:counts[r]], embed_grad, 1.0 / W)
+
+    @staticmethod
+    def _scatter_rows(ids, rows, embed_grad, scale):
+        from . import ops
+        ops.embedding_bwd(ids.contiguous(), rows.contiguous(), embed_grad, scale=scale)
 
     def on_stage(self, stage):
         """Host callback from the backward runner: grads of `stage` are enqueued on the compute stream."""
@@ -149,7 +172,7 @@ class FlatGradAllReduce:
 
 
 def attach(model, group=None, layers_per_bucket=1, split_embedding=True):
-    """Wire a HipQwen3ForCausalLM's backward stage callback to overlapped all-reduces."""
+    """Wire the backward stage callback of a flat-gradient model (HipQwen3ForCausalLM) to overlapped all-reduces."""
     split_embedding = split_embedding and model.dims.tie_word_embeddings
     plan = bucket_plan(model.layer_ranges, model.embed_range, model.norm_range, model.numel_flat, layers_per_bucket,
                        split_embedding)
@@ -158,3 +181,56 @@ def attach(model, group=None, layers_per_bucket=1, split_embedding=True):
     model._reducer = red
     model.no_sync = red.no_sync
     return red
+
+
+def speaks_flat_grad(model):
+    """True for models that own their gradient exchange through this module instead of torch DDP's autograd hooks:
+    one flat gradient buffer + a backward runner that reports finished stages (HipQwen3ForCausalLM)."""
+    return all(hasattr(model, a) for a in ("flat_grad", "layer_ranges", "embed_range", "norm_range", "numel_flat",
+                                           "_stage_cb"))
+
+
+class HipDataParallel(torch.nn.Module):
+    """What ``torch.nn.parallel.DistributedDataParallel`` is to an autograd model, for a flat-gradient model.
+
+    The reference gets data parallelism from accelerate, which wraps the student in torch DDP inside HF Trainer
+    (HF trainer.py:1615-1626) and skips the all-reduce on accumulation micro-batches through ``model.no_sync()``
+    (HF trainer.py:1757).  torch DDP cannot serve the HIP student: its reducer is driven by autograd hooks on the
+    parameters, and the backward runner writes the flat gradient buffer directly.  This wrapper is what
+    ``DistillationTrainer._wrap_model`` hands to the training loop instead: same ``.module`` / ``no_sync()`` surface
+    (accelerate's ``no_sync(model)`` finds it by duck typing), parameters broadcast from rank 0 at construction as
+    DDP does, gradient averaging by ``FlatGradAllReduce`` under the backward.  With one process it only forwards.
+    """
+
+    def __init__(self, module, group=None, layers_per_bucket=1, split_embedding=True, broadcast_params=True):
+        super().__init__()
+        self.module = module
+        self.reducer = None
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            if broadcast_params and getattr(module, "flat", None) is not None:
+                dist.broadcast(module.flat, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            self.reducer = attach(module, group, layers_per_bucket, split_embedding)
+
+    def forward(self, *args, **kwargs):
+        return self.module(*args, **kwargs)
+
+    def no_sync(self):
+        return self.reducer.no_sync() if self.reducer is not None else contextlib.nullcontext()
+
+    def zero_grad(self, set_to_none: bool = True):
+        return self.module.zero_grad(set_to_none)
+
+    # what Trainer reads from the object it trains
+    @property
+    def config(self):
+        return self.module.config
+
+    def gradient_checkpointing_enable(self, *a, **k):
+        return self.module.gradient_checkpointing_enable(*a, **k)
+
+
+def unwrap(model):
+    """The module under HipDataParallel / torch DDP / DataParallel (the model itself otherwise)."""
+    while isinstance(model, (HipDataParallel, torch.nn.parallel.DistributedDataParallel, torch.nn.DataParallel)):
+        model = model.module
+    return model

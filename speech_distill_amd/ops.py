@@ -318,10 +318,11 @@ class KDLossRowsFn(torch.autograd.Function):
         return grad, None, None, None, None, None, None, None
 
 
-def loss_rows(labels, speech_mask=None):
+def loss_rows(labels, speech_mask=None, right_padded=()):
     """Flat indices b*T+t of the rows the loss reads, and the label each one predicts: position t < T-1 whose
-    NEXT label is not -100 (and whose next mask bit is set) -- distillation_loss.py:31-45.  One host sync (the
-    row count sizes the lm_head GEMMs)."""
+    NEXT label is not -100 (and whose next mask bit is set) -- distillation_loss.py:31-45.  One host read (the
+    row count sizes the lm_head GEMMs); ``right_padded``: attention masks to validate in that same read -- raises
+    ValueError if one of them is not a valid-prefix mask (see HipQwen3ForCausalLM.forward)."""
     B, T = labels.shape
     nxt = torch.full_like(labels, -100)
     nxt[:, :-1] = labels[:, 1:]
@@ -330,7 +331,23 @@ def loss_rows(labels, speech_mask=None):
         m = torch.zeros_like(valid)
         m[:, :-1] = speech_mask.to(labels.device)[:, 1:] != 0
         valid &= m
-    rows = torch.nonzero(valid.reshape(-1)).reshape(-1)
+    flat = valid.reshape(-1)
+    masks = [m for m in right_padded if m is not None]
+    if labels.is_cuda:
+        from .qwen3 import left_padded
+        host = torch.stack([flat.sum()] + [left_padded(m.to(labels.device)).to(torch.int64) for m in masks]).tolist()
+        if any(host[1:]):
+            raise ValueError("attention_mask is not right-padded (a 1 follows a 0): the HIP attention kernels take a "
+                             "valid-prefix length per sequence, as ProcessedDataCollator produces (data.py:280-327)")
+        try:
+            rows = torch.nonzero_static(flat, size=int(host[0])).reshape(-1)
+        except (NotImplementedError, RuntimeError):
+            rows = torch.nonzero(flat).reshape(-1)
+    else:
+        from .qwen3 import left_padded
+        if any(bool(left_padded(m)) for m in masks):
+            raise ValueError("attention_mask is not right-padded")
+        rows = torch.nonzero(flat).reshape(-1)
     return rows, nxt.reshape(-1)[rows]
 
 

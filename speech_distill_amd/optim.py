@@ -58,6 +58,21 @@ class FlatAdamW(torch.optim.Optimizer):
                        g["eps"], wd if is_mat else 0.0, self._step, ss, clip)
         return None
 
+    def state_dict(self):
+        """HF Trainer checkpoints ``optimizer.state_dict()`` (optimizer.pt): the flat bf16 moments + step count."""
+        sd = super().state_dict()
+        sd["flat"] = {"exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "step": self._step}
+        return sd
+
+    def load_state_dict(self, state_dict):
+        state_dict = dict(state_dict)
+        flat = state_dict.pop("flat", None)
+        super().load_state_dict(state_dict)
+        if flat is not None:
+            self.exp_avg.copy_(flat["exp_avg"])
+            self.exp_avg_sq.copy_(flat["exp_avg_sq"])
+            self._step = int(flat["step"])
+
     def grad_norm(self):
         """Global gradient norm seen by the last step (device tensor)."""
         return self._sumsq.sqrt()

@@ -47,12 +47,28 @@ class Qwen3Dims:
         return self.num_key_value_heads * self.head_dim
 
     @classmethod
+    def from_hf_config(cls, c):
+        """From an HF Qwen3Config (transformers 4.x keeps ``rope_theta`` on the config, 5.x in ``rope_parameters``)."""
+        rope = getattr(c, "rope_theta", None)
+        if rope is None:
+            rope = (getattr(c, "rope_parameters", None) or {}).get("rope_theta", 1e6)
+        return cls(c.vocab_size, c.hidden_size, c.intermediate_size, c.num_hidden_layers, c.num_attention_heads,
+                   c.num_key_value_heads, getattr(c, "head_dim", None) or 128, c.rms_norm_eps, float(rope),
+                   bool(c.tie_word_embeddings))
+
+    @classmethod
     def student_06b(cls):  # public Qwen3-0.6B shape, vocab expanded to the teacher's (prepare_student.py:31,79-82)
         return cls(159488, 1024, 3072, 28, 16, 8)
 
     @classmethod
     def teacher_17b(cls):  # soulxpodcast/config.py:12-42
         return cls(159488, 2048, 6144, 28, 16, 8)
+
+
+def left_padded(attention_mask):
+    """0-d bool tensor: some row has a 1 after a 0, i.e. the mask is not a valid-prefix (right-padded) mask."""
+    am = attention_mask != 0
+    return (am[:, 1:] & ~am[:, :-1]).any()
 
 
 class _Holder(nn.Module):
@@ -166,10 +182,36 @@ class HipQwen3ForCausalLM(nn.Module):
         self._stage_cb = None  # python callable(stage) set by the data-parallel wrapper
         self.overlap_dw = True
         self._side_stream = None
+        # The attention kernels take a valid-prefix length per sequence, i.e. RIGHT padding -- what the collator emits
+        # (data.py:280-327).  ``forward`` checks the mask for that (one host read); a caller that has already checked
+        # (DistillationTrainer folds it into the row-count read it needs anyway) passes ``padding_checked=True``.
+        self.validate_padding = True
         if init_std:
             self.init_weights(seed, init_std)
 
     # ------------------------------------------------------------------------------- construction
+    def _apply(self, fn, recurse=True):
+        """``.to(device)`` / ``.cuda()`` (HF Trainer moves the model to ``args.device``): move the FLAT buffers and
+        re-point the HF-named parameters at them, so they stay views of one buffer.  Other dtypes are refused."""
+        new_flat = fn(self.flat)
+        if new_flat.dtype != torch.bfloat16:
+            raise TypeError("HipQwen3ForCausalLM holds bf16 parameters (train.py:174 loads the student in bf16)")
+        if new_flat.device == self.flat.device:
+            return self
+        self.flat = new_flat
+        for name, (o, n, shape) in self._slices.items():
+            self._params[name].data = new_flat[o:o + n].view(shape)
+        if self.flat_grad is not None:
+            self.flat_grad = fn(self.flat_grad)
+            self._cgrads, self._cglayers = self._c_struct(self.flat_grad)
+            if self._grads_live:
+                for name, (o, n, shape) in self._slices.items():
+                    self._params[name].grad = self.flat_grad[o:o + n].view(shape)
+        self._anchor = torch.zeros((), device=new_flat.device, requires_grad=True)
+        self._cparams, self._clayers = self._c_struct(self.flat)
+        self._rope, self._side_stream = {}, None
+        return self
+
     @staticmethod
     def _hf_config(d):
         try:
@@ -227,6 +269,95 @@ class HipQwen3ForCausalLM(nn.Module):
             if name == "lm_head.weight" and name not in sd:
                 continue
             p.copy_(sd[name].to(torch.bfloat16))
+
+    # ------------------------------------------------------------------------------ checkpointing
+    # The reference checkpoints through HF Trainer (save_strategy="epoch", load_best_model_at_end=True,
+    # save_total_limit=3: train.py:341-345), i.e. ``save_pretrained`` of an HF Qwen3ForCausalLM: a directory with
+    # ``config.json`` + ``model.safetensors`` whose keys are the HF names and which does NOT hold ``lm_head.weight``
+    # when the head is tied (HF drops ``_tied_weights_keys``).  The same directory is written and read here.
+    _tied_weights_keys = {"lm_head.weight": "model.embed_tokens.weight"}
+
+    def _tied_head_key(self, prefix=""):
+        return prefix + "lm_head.weight" if self.dims.tie_word_embeddings else None
+
+    def state_dict(self, *args, destination=None, prefix="", keep_vars=False):
+        """HF key names -> tensors (views of the flat buffer).  A tied ``lm_head.weight`` is left out, as in an HF
+        checkpoint: it is the same memory as ``model.embed_tokens.weight`` and safetensors refuses aliases."""
+        sd = super().state_dict(*args, destination=destination, prefix=prefix, keep_vars=keep_vars)
+        tied = self._tied_head_key(prefix)
+        if tied is not None:
+            sd.pop(tied, None)
+        return sd
+
+    def load_state_dict(self, state_dict, strict=True, assign=False):
+        """Copy HF-named tensors (any float dtype / device) into the flat buffer.  Returns torch's
+        ``_IncompatibleKeys``; a tied ``lm_head.weight`` is neither required nor, when present, unexpected
+        (it must then equal the embedding, which is what gets loaded)."""
+        from torch.nn.modules.module import _IncompatibleKeys
+        tied = self._tied_head_key()
+        want = [k for k in self._params if k != tied] if tied else list(self._params)
+        if tied and "lm_head.weight" in self._params:
+            want = [k for k in want if k != "lm_head.weight"]
+        missing = [k for k in want if k not in state_dict]
+        unexpected = [k for k in state_dict if k not in self._params and k != tied]
+        bad = [k for k in want if k in state_dict and tuple(state_dict[k].shape) != tuple(self._params[k].shape)]
+        if bad:
+            raise RuntimeError("size mismatch for " + ", ".join(
+                f"{k}: checkpoint {tuple(state_dict[k].shape)} vs model {tuple(self._params[k].shape)}" for k in bad))
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"Error(s) in loading state_dict for {type(self).__name__}: missing {missing}, "
+                               f"unexpected {unexpected}")
+        with torch.no_grad():
+            for k in want:
+                if k in state_dict:
+                    self._params[k].copy_(state_dict[k])
+        return _IncompatibleKeys(missing, unexpected)
+
+    def save_pretrained(self, save_directory, state_dict=None, safe_serialization=True, **kwargs):
+        """HF-loadable checkpoint directory: ``config.json`` (+ ``model.safetensors`` / ``pytorch_model.bin``).
+        ``AutoModelForCausalLM.from_pretrained(dir)`` and ``HipQwen3ForCausalLM.from_pretrained(dir)`` both read it."""
+        import os
+        os.makedirs(save_directory, exist_ok=True)
+        sd = self.state_dict() if state_dict is None else dict(state_dict)
+        tied = self._tied_head_key()
+        if tied:
+            sd.pop(tied, None)
+        sd = {k: v.detach().contiguous() for k, v in sd.items()}
+        if hasattr(self.config, "save_pretrained"):
+            if getattr(self.config, "architectures", None) is None:
+                self.config.architectures = ["Qwen3ForCausalLM"]
+            self.config.save_pretrained(save_directory)
+        if safe_serialization:
+            from safetensors.torch import save_file
+            save_file(sd, os.path.join(save_directory, "model.safetensors"), metadata={"format": "pt"})
+        else:
+            torch.save(sd, os.path.join(save_directory, "pytorch_model.bin"))
+
+    @classmethod
+    def from_pretrained(cls, directory, device="cuda", **kwargs):
+        """Build from an HF checkpoint directory (what ``save_pretrained`` above or HF itself wrote); local only."""
+        import json
+        import os
+        from transformers import AutoConfig
+        c = AutoConfig.from_pretrained(directory)
+        dims = Qwen3Dims.from_hf_config(c)
+        m = cls(dims, device=device, config=c, init_std=0)
+        st = os.path.join(directory, "model.safetensors")
+        idx = os.path.join(directory, "model.safetensors.index.json")
+        if os.path.isfile(st):
+            from safetensors.torch import load_file
+            m.load_state_dict(load_file(st, device="cpu"))
+        elif os.path.isfile(idx):
+            from safetensors.torch import load_file
+            files = sorted(set(json.load(open(idx))["weight_map"].values()))
+            sd = {}
+            for f in files:
+                sd.update(load_file(os.path.join(directory, f), device="cpu"))
+            m.load_state_dict(sd)
+        else:
+            m.load_state_dict(torch.load(os.path.join(directory, "pytorch_model.bin"), map_location="cpu",
+                                         weights_only=True))
+        return m
 
     # ------------------------------------------------------------------ HF/Trainer protocol no-ops
     def gradient_checkpointing_enable(self, *a, **k):
@@ -331,7 +462,13 @@ class HipQwen3ForCausalLM(nn.Module):
                 raise ValueError("logit_rows must be a non-empty 1-D tensor of at most B*T row indices")
         kv_len = None
         if attention_mask is not None:
-            kv_len = attention_mask.to(ids.device).sum(-1).to(torch.int32).contiguous()  # right padding (data.py:292-327)
+            am = attention_mask.to(ids.device)
+            if am.shape != ids.shape:
+                raise ValueError(f"attention_mask {tuple(am.shape)} != input_ids {tuple(ids.shape)}")
+            if self.validate_padding and not kwargs.get("padding_checked", False) and bool(left_padded(am)):
+                raise ValueError("attention_mask is not right-padded (a 1 follows a 0): the HIP attention kernels take a "
+                                 "valid-prefix length per sequence, as ProcessedDataCollator produces (data.py:280-327)")
+            kv_len = am.sum(-1).to(torch.int32).contiguous()
         if torch.is_grad_enabled() and any(p.requires_grad for p in self._params.values()):
             logits = _DecoderFn.apply(self._anchor, ids, kv_len, self, rows)
         else:

@@ -7,10 +7,12 @@ present  ->  on-the-fly log-softmax + top-K unless the teacher is quantized or t
 DistillationLoss  ->  log {student_loss, teacher_loss, distill_loss} when
 ``state.global_step % args.logging_steps == 0``  ->  ``loss`` or ``(loss, outputs)``.
 """
+import os
+
 import torch
 from transformers import Trainer
 
-from . import ops
+from . import ddp, ops
 from .distillation_loss import DistillationLoss
 from .qwen3 import HipQwen3ForCausalLM
 
@@ -37,6 +39,37 @@ class DistillationTrainer(Trainer):
         # afterwards; loss and gradients are the same, the head is ~(masked fraction) cheaper.  Needs one host sync
         # per step for the row count.  Off: the full [B,T,V] path; return_outputs=True always uses the full path.
         self.compact_head = True
+        self._hip_dp = None
+
+    # ------------------------------------------------------------------------------ HF Trainer plumbing
+    def _wrap_model(self, model, training=True, dataloader=None):
+        """HF trainer.py:1602-1626: a model this hook leaves unwrapped goes through ``accelerator.prepare``, which under
+        torchrun wraps it in torch DDP (the reference's data parallelism) and under ``bf16=True`` wraps ``forward`` to
+        copy every bf16 output to fp32.  Neither fits a flat-gradient model (see ``ddp.HipDataParallel``): its
+        gradients never pass autograd hooks, and its [.,V] logits are consumed as bf16 by the loss kernel.  Such a
+        model is handed to the loop inside ``HipDataParallel`` instead -- the one owner of gradient averaging, with the
+        ``no_sync()`` accelerate looks for on accumulation micro-batches; HF then prepares only the optimizer."""
+        if isinstance(model, ddp.HipDataParallel):
+            return model
+        if ddp.speaks_flat_grad(model):
+            if self._hip_dp is None or self._hip_dp.module is not model:
+                self._hip_dp = ddp.HipDataParallel(model)
+            return self._hip_dp
+        return super()._wrap_model(model, training=training, dataloader=dataloader)
+
+    def _save(self, output_dir=None, state_dict=None):
+        """HF trainer.py `_save`: a model that is not a PreTrainedModel gets a bare ``model.safetensors``.  The
+        reference's checkpoints (save_strategy="epoch", train.py:341-345) are ``save_pretrained`` directories
+        (``config.json`` + weights, tied head left out) -- write the same for a model that offers it."""
+        core = ddp.unwrap(self.model)
+        if not hasattr(core, "save_pretrained") or isinstance(core, _pretrained_types()):
+            return super()._save(output_dir, state_dict)
+        output_dir = output_dir if output_dir is not None else self.args.output_dir
+        os.makedirs(output_dir, exist_ok=True)
+        core.save_pretrained(output_dir, state_dict=state_dict)
+        if self.processing_class is not None and hasattr(self.processing_class, "save_pretrained"):
+            self.processing_class.save_pretrained(output_dir)
+        torch.save(self.args, os.path.join(output_dir, "training_args.bin"))
 
     def _teacher_pass(self, inputs, teacher_input_ids, teacher_attention_mask, vocab_size, rows=None):
         """train.py:60-94: teacher no-grad forward, then on-the-fly top-K unless quantized / top_k <= 0.
@@ -45,9 +78,10 @@ class DistillationTrainer(Trainer):
             extra = {"logit_rows": rows} if rows is not None and isinstance(self.teacher_model, HipQwen3ForCausalLM) else {}
             if teacher_input_ids is not None:
                 teacher_outputs = self.teacher_model(input_ids=teacher_input_ids, attention_mask=teacher_attention_mask,
-                                                     **extra)
+                                                     **extra, **getattr(self, "_teacher_kw", {}))
             else:
-                teacher_outputs = self.teacher_model(**{k: v for k, v in inputs.items() if k != "labels"}, **extra)
+                teacher_outputs = self.teacher_model(**{k: v for k, v in inputs.items() if k != "labels"}, **extra,
+                                                     **getattr(self, "_teacher_kw", {}))
             teacher_logits = teacher_outputs.logits
             if rows is not None and not extra:
                 teacher_logits = teacher_logits.reshape(-1, teacher_logits.size(-1))[rows]
@@ -64,18 +98,27 @@ class DistillationTrainer(Trainer):
         teacher_top_k_i = inputs.pop("teacher_top_k_i", None)
 
         need_teacher = teacher_top_k_v is None and self.teacher_model is not None
-        vocab = getattr(getattr(model, "dims", None), "vocab_size", None)  # only our own model type is overlapped
+        # `model` is what the loop trains (HipDataParallel / torch DDP / the bare module); `core` is the module itself
+        core = ddp.unwrap(model)
+        hip_student = isinstance(core, HipQwen3ForCausalLM)
+        hip_teacher = isinstance(self.teacher_model, HipQwen3ForCausalLM)
+        vocab = getattr(getattr(core, "dims", None), "vocab_size", None)  # only our own model type is overlapped
         side = None
         ids = inputs.get("input_ids")
         rows = row_labels = None
         lab = inputs.get("labels")
-        if (self.compact_head and not return_outputs and isinstance(model, HipQwen3ForCausalLM) and lab is not None
+        checked = {}
+        if (self.compact_head and not return_outputs and hip_student and lab is not None
                 and lab.is_cuda and isinstance(self.distill_loss_fn, DistillationLoss)):
-            rows, row_labels = ops.loss_rows(lab, speech_mask)
+            # the one host read of the step: the row count, and (same read) that the masks are right-padded
+            rows, row_labels = ops.loss_rows(lab, speech_mask, right_padded=(
+                inputs.get("attention_mask"), teacher_attention_mask if hip_teacher else None))
+            checked = {"padding_checked": True}
             if rows.numel() == 0:  # N == 0: the full path returns the reference's zeros (distillation_loss.py:47-53)
                 rows = row_labels = None
+        self._teacher_kw = checked if hip_teacher else {}
         if (need_teacher and self.overlap_teacher and vocab is not None and ids is not None and ids.is_cuda
-                and isinstance(self.teacher_model, HipQwen3ForCausalLM)):
+                and hip_teacher):
             if self._teacher_stream is None:
                 self._teacher_stream = torch.cuda.Stream(device=ids.device)
             side = self._teacher_stream
@@ -88,7 +131,7 @@ class DistillationTrainer(Trainer):
             teacher_top_k_v = teacher_top_k_v.to(dev).reshape(-1, teacher_top_k_v.size(-1))[rows]
             teacher_top_k_i = teacher_top_k_i.to(dev).reshape(-1, teacher_top_k_i.size(-1))[rows]
 
-        outputs = model(**inputs) if rows is None else model(**inputs, logit_rows=rows)  # train.py:54
+        outputs = model(**inputs) if rows is None else model(**inputs, logit_rows=rows, **checked)  # train.py:54
         student_logits = outputs.logits
         labels = inputs.pop("labels", None)
 
@@ -102,7 +145,7 @@ class DistillationTrainer(Trainer):
         teacher_logits = teacher_logits_local
 
         if isinstance(self.distill_loss_fn, DistillationLoss):
-            self.distill_loss_fn.inplace_grad = (not return_outputs) and isinstance(model, HipQwen3ForCausalLM)
+            self.distill_loss_fn.inplace_grad = (not return_outputs) and hip_student
         if rows is not None:
             loss, task_loss, distill_loss, teacher_loss = self.distill_loss_fn.forward_rows(
                 student_logits, row_labels, teacher_logits=teacher_logits, teacher_top_k_v=teacher_top_k_v,
@@ -118,3 +161,8 @@ class DistillationTrainer(Trainer):
                                 distill_loss.detach().float()]).tolist()
             self.log({"student_loss": vals[0], "teacher_loss": vals[1], "distill_loss": vals[2]})
         return (loss, outputs) if return_outputs else loss
+
+
+def _pretrained_types():
+    from transformers import PreTrainedModel
+    return (PreTrainedModel,)
