@@ -290,15 +290,18 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16* __restrict_
 }
 
 // ----------------------------------------------------------------------------------------------- dQ
-// Same decomposition as forward.  dQ^T[d][q] = scale * sum_key K^T[d][key] dS^T[key][q].
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ Kp,
+// Same decomposition as forward, 8 waves: waves w and w+4 own the same 32 query rows and split the K/V tiles
+// (half = w>>2 takes tiles t = 2i + half) through their own double buffers; the two partial dQ^T are added through
+// LDS at the end in a fixed order.  dQ^T[d][q] = scale * sum_key K^T[d][key] dS^T[key][q].
+__global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ Kp,
                                                           const bf16* __restrict__ Vp, const bf16* __restrict__ dO,
                                                           const float* __restrict__ LSE, const float* __restrict__ delta,
                                                           bf16* __restrict__ dQ, const int* __restrict__ kv_len, long ldq,
                                                           long ldk, long ldv, long ldo, long lddq, int T, int Hq, int Hkv,
                                                           float scale) {
-  __shared__ __attribute__((aligned(16))) char smem[6 * TILE];
-  const int lane = lane_id(), w = wave_id_uniform();
+  __shared__ __attribute__((aligned(16))) char smem[8 * TILE];  // 2 halves x 2 stages x (K,V)
+  const int lane = lane_id(), w8 = wave_id_uniform();
+  const int half = w8 >> 2, w = w8 & 3;
   const int qt = gridDim.x - 1 - blockIdx.x;
   const int hq = blockIdx.y, b = blockIdx.z;
   const int hkv = hq / (Hq / Hkv);
@@ -330,29 +333,28 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict
 
   const int kv_hi = min(q0 + 128, T);
   const int nkv = (kv_hi + 63) / 64;
+  const int nit = (nkv + 1) >> 1;  // trips of both halves; half 1 idles through the last one when nkv is odd
   TileDma kd, vd;
   kd.init(kb, ldk, T, w, lane);
   vd.init(vb, ldv, T, w, lane);
-  kd.issue(0, smem, w);
-  vd.issue(0, smem + TILE, w);
-  kd.issue(64, smem + 2 * TILE, w);
-  vd.issue(64, smem + 3 * TILE, w);
-  int cur_i = 0, nxt_i = 2;
-  for (int t = 0; t < nkv; ++t) {
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+  char* ring = smem + half * 4 * TILE;
+  kd.issue(half * 64, ring, w);
+  vd.issue(half * 64, ring + TILE, w);
+  int cur_i = 0;
+  for (int i = 0; i < nit; ++i) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // my half's tile i has landed; everybody is done reading the other stage
     asm volatile("" ::: "memory");
     {
-      char* nx = smem + nxt_i * 2 * TILE;
-      kd.issue((t + 2) * 64, nx, w);
-      vd.issue((t + 2) * 64, nx + TILE, w);
+      char* nx = ring + (cur_i ^ 1) * 2 * TILE;
+      kd.issue((2 * (i + 1) + half) * 64, nx, w);
+      vd.issue((2 * (i + 1) + half) * 64, nx + TILE, w);
     }
-    const char* ks = smem + cur_i * 2 * TILE;
+    const char* ks = ring + cur_i * 2 * TILE;
     const char* vs = ks + TILE;
-    cur_i = (cur_i == 2) ? 0 : cur_i + 1;
-    nxt_i = (nxt_i == 2) ? 0 : nxt_i + 1;
-    const int kv0 = t * 64;
-    if (kv0 <= q0w + 31) {
+    cur_i ^= 1;
+    const int kv0 = (2 * i + half) * 64;
+    if (kv0 < kv_hi && kv0 <= q0w + 31) {
 #pragma unroll
       for (int kb2 = 0; kb2 < 2; ++kb2) {
         f32x16 s, dp;
@@ -380,7 +382,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict
       }
     }
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the tail tiles before the ring is reused
+  __syncthreads();
+  float* xo = (float*)smem + (long)w * 64 * 64;  // [w][slot][lane] floats
+  if (half == 1) {
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) xo[(db * 16 + e) * 64 + lane] = acc[db][e];
+  }
+  __syncthreads();
+  if (half == 1) return;
   if (q < T) {
     bf16* orow = dQ + (tok0 + q) * lddq + hq * D;
 #pragma unroll
@@ -389,43 +401,55 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict
       for (int g4 = 0; g4 < 4; ++g4) {
         bf16x4 v;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = (bf16)(acc[db][4 * g4 + e] * scale);
+        for (int e = 0; e < 4; ++e) v[e] = (bf16)((acc[db][4 * g4 + e] + xo[(db * 16 + 4 * g4 + e) * 64 + lane]) * scale);
         *(bf16x4*)(orow + db * 32 + 8 * g4 + 4 * h) = v;
       }
   }
 }
 
 // -------------------------------------------------------------------------------------------- dK, dV
-// grid (ceil(T/128), Hkv, B): wave w owns keys k0 + 32w .. +31 of kv head hkv; loops over the G query
-// heads of the group and over 64-row query tiles at or below the diagonal.
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ Kp,
+// grid (ceil(T/128), Hkv, B), 512 threads = 8 waves, two per SIMD.  Waves w and w+4 own the SAME 32 keys
+// k0 + 32w .. +31 of kv head hkv and split every 64-row (Q, dO) tile between them: half = w>>2 takes query rows
+// 32*half .. +31 of each tile.  The block loops over the G query heads of the group and over the 64-row query
+// tiles at or below the diagonal; the two partial (dK^T, dV^T) of a key are added through LDS at the end in a
+// fixed order (no atomics, deterministic).  With ONE wave per SIMD a wave ran its DMA issue, LDS reads, 64 MFMAs
+// and the exp/mask VALU of a tile strictly one after the other (~3.5 us per tile for ~1 us of MFMA, 63 us per
+// launch at B=4,T=512); two independent waves per SIMD overlap those phases.  To fit two waves into the SIMD's 512
+// registers the block's K and V (128 keys) live in LDS instead of registers (64 KiB), beside a 2-stage (Q, dO) ring
+// (64 KiB): waves 0-3 stage K and the Q tiles, waves 4-7 stage V and the dO tiles.
+__global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ Kp,
                                                            const bf16* __restrict__ Vp, const bf16* __restrict__ dO,
                                                            const float* __restrict__ LSE, const float* __restrict__ delta,
                                                            bf16* __restrict__ dK, bf16* __restrict__ dV,
                                                            const int* __restrict__ kv_len, long ldq, long ldk, long ldv,
                                                            long ldo, long lddk, long lddv, int T, int Hq, int Hkv,
                                                            float scale) {
-  __shared__ __attribute__((aligned(16))) char smem[6 * TILE];  // 3 stages x (Q, dO)
-  __shared__ __attribute__((aligned(16))) float stat[3][2][64];  // [stage][lse2|delta][q row]
-  const int lane = lane_id(), w = wave_id_uniform();
+  // [K 128 rows | V 128 rows | stage 0: Q, dO | stage 1: Q, dO | stat[2 stages][lse2|delta][64 q rows]]
+  // (ONE __shared__ object: a second one beside an LDS-DMA target makes hipcc drain vmcnt before LDS reads)
+  __shared__ __attribute__((aligned(16))) char smem[8 * TILE + 1024];
+  const int lane = lane_id(), w8 = wave_id_uniform();
+  const int half = w8 >> 2, w = w8 & 3;
   const int hkv = blockIdx.y, b = blockIdx.z;
   const int G = Hq / Hkv;
-  const int k0 = blockIdx.x * 128, k0w = k0 + 32 * w;
+  const int k0 = blockIdx.x * 128;  // block 0 sees every query tile: heaviest first
+  const int k0w = k0 + 32 * w;
   const int r = lane & 31, h = lane >> 5;
   const int klen = kv_len ? max(1, min(kv_len[b], T)) : T;
   const long tok0 = (long)b * T;
-  const bf16* kb = Kp + tok0 * ldk + hkv * D;
-  const bf16* vb = Vp + tok0 * ldv + hkv * D;
   const int key = k0w + r;  // this lane's key (column of S)
-  const int keyc = key < T ? key : T - 1;
-  bf16x8 kf[8], vf[8];
-#pragma unroll
-  for (int st = 0; st < 8; ++st) {
-    kf[st] = *(const bf16x8*)(kb + (long)keyc * ldk + 16 * st + 8 * h);
-    vf[st] = *(const bf16x8*)(vb + (long)keyc * ldv + 16 * st + 8 * h);
-  }
   const bool key_ok = key < klen;  // padded / out-of-range keys receive no probability
   const float c = scale * LOG2E;
+  char* const ksm = smem;
+  char* const vsm = smem + 2 * TILE;
+  char* const ring = smem + 4 * TILE;
+  float* const stat = (float*)(smem + 8 * TILE);  // [stage][which][64]
+  {
+    TileDma kvd;
+    kvd.init((half ? Vp + tok0 * ldv : Kp + tok0 * ldk) + hkv * D, half ? ldv : ldk, T, w, lane);
+    char* dst = half ? vsm : ksm;
+    kvd.issue(k0, dst, w);
+    kvd.issue(k0 + 64, dst + TILE, w);
+  }
   f32x16 dk[4], dv[4];
 #pragma unroll
   for (int db = 0; db < 4; ++db)
@@ -436,92 +460,102 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restric
   const int nqt = (T + 63) / 64;
   const int per_head = nqt - qt0;
   const int nit = G * per_head;
-  // 3-stage (Q, dO) ring, counted vmcnt + raw barrier (see attn_fwd_kernel).  The LSE / delta values of a
-  // stage are loaded into a register BEFORE that stage's DMA is issued, so the compiler's wait for them
-  // (ahead of the ds_write) does not also drain the DMA that was just started.
   const int st_i = threadIdx.x & 63, st_which = (threadIdx.x >> 6) & 1;
-  auto stage_it = [&](int it, int buf) -> float {
+  // LSE / delta of the 64 query rows of tile `it` (threads 0..127), loaded an iteration before they are written to LDS
+  auto load_stat = [&](int it) -> float {
+    if (threadIdx.x >= 128) return 0.f;
+    const int itc = it < nit ? it : nit - 1;
+    const int hq = hkv * G + itc / per_head;
+    int qq = (qt0 + itc % per_head) * 64 + st_i;
+    qq = qq < T ? qq : T - 1;
+    const long o = ((long)b * Hq + hq) * T + qq;
+    return st_which ? delta[o] : LSE[o] * LOG2E;
+  };
+  // one tile = Q rows (waves 0-3) + dO rows (waves 4-7) of query head g, rows qt*64 .. +63; past-the-end: zeros
+  auto stage_it = [&](int it, int buf) {
     const bool real = it < nit;
     const int itc = real ? it : nit - 1;
-    const int g = itc / per_head, qt = real ? qt0 + itc % per_head : nqt + 1;  // past-the-end tile: rows read as zeros
+    const int g = itc / per_head, qt = real ? qt0 + itc % per_head : nqt + 1;
     const int hq = hkv * G + g;
-    char* dst = smem + buf * 2 * TILE;
-    float sv = 0.f;
-    if (threadIdx.x < 128) {
-      int qq = qt * 64 + st_i;
-      qq = qq < T ? qq : T - 1;
-      const long o = ((long)b * Hq + hq) * T + qq;
-      sv = st_which ? delta[o] : LSE[o] * LOG2E;
-    }
-    TileDma qd, od;  // the query head changes with `it`: descriptors are rebuilt (scalar work only)
-    qd.init(Q + tok0 * ldq + hq * D, ldq, T, w, lane);
-    od.init(dO + tok0 * ldo + hq * D, ldo, T, w, lane);
-    qd.issue(qt * 64, dst, w);
-    od.issue(qt * 64, dst + TILE, w);
-    return sv;  // written to stat[buf] one iteration later, so that its wait never drains the DMA issued above
+    TileDma d;  // the query head changes with `it`: the descriptor is rebuilt (scalar work only)
+    d.init((half ? dO + tok0 * ldo : Q + tok0 * ldq) + hq * D, half ? ldo : ldq, T, w, lane);
+    d.issue(qt * 64, ring + buf * 2 * TILE + half * TILE, w);
   };
   {
-    const float sv0 = stage_it(0, 0);
-    if (threadIdx.x < 128) stat[0][st_which][st_i] = sv0;
+    const float sv0 = load_stat(0);
+    stage_it(0, 0);
+    if (threadIdx.x < 128) stat[st_which * 64 + st_i] = sv0;
   }
-  float pend_sv = stage_it(1, 1);
-  int pend_buf = 1;
-  int cur_i = 0, nxt_i = 2;
+  float pend_sv = load_stat(1);
   for (int it = 0; it < nit; ++it) {
-    asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    const int buf = it & 1;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // tile `it` (and K, V) landed; everybody has finished reading the other stage
     asm volatile("" ::: "memory");
-    if (threadIdx.x < 128) stat[pend_buf][st_which][st_i] = pend_sv;
-    pend_sv = stage_it(it + 2, nxt_i);
-    pend_buf = nxt_i;
-    const int buf = cur_i;
-    const char* qs = smem + buf * 2 * TILE;
+    if (threadIdx.x < 128) stat[(buf ^ 1) * 128 + st_which * 64 + st_i] = pend_sv;
+    pend_sv = load_stat(it + 2);
+    stage_it(it + 1, buf ^ 1);
+    const char* qs = ring + buf * 2 * TILE;
     const char* dos = qs + TILE;
-    cur_i = (cur_i == 2) ? 0 : cur_i + 1;
-    nxt_i = (nxt_i == 2) ? 0 : nxt_i + 1;
-    const int qbase = (qt0 + it % per_head) * 64;
+    const int qb0 = (qt0 + it % per_head) * 64 + 32 * half;
+    if (qb0 + 31 < k0w) continue;  // wave-uniform: this wave's 32 query rows are all above its keys
+    f32x16 s, dp;
 #pragma unroll
-    for (int qb2 = 0; qb2 < 2; ++qb2) {
-      const int qb0 = qbase + qb2 * 32;
-      if (qb0 + 31 < k0w) continue;  // wave-uniform: the whole 32-row block is above this wave's keys
-      f32x16 s, dp;
+    for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
 #pragma unroll
-      for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
+    for (int st = 0; st < 8; ++st) {
+      s = mfma32(row_frag(qs, 32 * half, st, lane), row_frag(ksm, 32 * w, st, lane), s);     // S  = Q K^T (rows q, col key)
+      dp = mfma32(row_frag(dos, 32 * half, st, lane), row_frag(vsm, 32 * w, st, lane), dp);  // dP = dO V^T
+    }
 #pragma unroll
-      for (int st = 0; st < 8; ++st) {
-        s = mfma32(row_frag(qs, qb2 * 32, st, lane), kf[st], s);      // S  = Q K^T   (rows q, col key)
-        dp = mfma32(row_frag(dos, qb2 * 32, st, lane), vf[st], dp);   // dP = dO V^T
-      }
-      f32x16 ds;
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const f32x4 l2 = *(const f32x4*)&stat[buf * 128 + 32 * half + 8 * g4 + 4 * h];
+      const f32x4 dl = *(const f32x4*)&stat[buf * 128 + 64 + 32 * half + 8 * g4 + 4 * h];
 #pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        const f32x4 l2 = *(const f32x4*)&stat[buf][0][qb2 * 32 + 8 * g4 + 4 * h];
-        const f32x4 dl = *(const f32x4*)&stat[buf][1][qb2 * 32 + 8 * g4 + 4 * h];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int qq = qb0 + 8 * g4 + 4 * h + e;
-          const bool vis = key_ok && key <= qq && qq < T;
-          const float p = vis ? __builtin_amdgcn_exp2f(s[4 * g4 + e] * c - l2[e]) : 0.f;
-          s[4 * g4 + e] = p;
-          ds[4 * g4 + e] = p * (dp[4 * g4 + e] - dl[e]);
-        }
-      }
-#pragma unroll
-      for (int ss = 0; ss < 2; ++ss) {
-        const bf16x8 pf = acc_frag(s, ss), df = acc_frag(ds, ss);
-        bf16x8 dot4[4], qt4[4];
-        tr_frag4(dos, qb2 * 32 + 16 * ss, lane, dot4);
-        tr_frag4(qs, qb2 * 32 + 16 * ss, lane, qt4);
-#pragma unroll
-        for (int db = 0; db < 4; ++db) {
-          dv[db] = mfma32(dot4[db], pf, dv[db]);  // dV^T += dO^T P
-          dk[db] = mfma32(qt4[db], df, dk[db]);   // dK^T += Q^T dS
-        }
+      for (int e = 0; e < 4; ++e) {
+        const int qq = qb0 + 8 * g4 + 4 * h + e;
+        const bool vis = key_ok && key <= qq && qq < T;
+        const float p = vis ? __builtin_amdgcn_exp2f(s[4 * g4 + e] * c - l2[e]) : 0.f;
+        s[4 * g4 + e] = p;
+        dp[4 * g4 + e] = p * (dp[4 * g4 + e] - dl[e]);  // dS (without the d^-1/2 factor)
       }
     }
+#pragma unroll
+    for (int ss = 0; ss < 2; ++ss) {
+      bf16x8 t4[4];
+      const bf16x8 pf = acc_frag(s, ss);
+      tr_frag4(dos, 32 * half + 16 * ss, lane, t4);
+#pragma unroll
+      for (int db = 0; db < 4; ++db) dv[db] = mfma32(t4[db], pf, dv[db]);  // dV^T += dO^T P
+      const bf16x8 df = acc_frag(dp, ss);
+      tr_frag4(qs, 32 * half + 16 * ss, lane, t4);
+#pragma unroll
+      for (int db = 0; db < 4; ++db) dk[db] = mfma32(t4[db], df, dk[db]);  // dK^T += Q^T dS
+    }
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (key < T) {
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // drain the tail tile before LDS is reused
+  __syncthreads();
+  // merge: half 1 parks dK^T then dV^T of its keys in LDS ([w][slot][lane] floats, 16 KiB per wave and round)
+  float* xo = (float*)smem + (long)w * 64 * 64;
+#pragma unroll
+  for (int round = 0; round < 2; ++round) {
+    f32x16* acc = round ? dv : dk;
+    if (half == 1) {
+#pragma unroll
+      for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) xo[(db * 16 + e) * 64 + lane] = acc[db][e];
+    }
+    __syncthreads();
+    if (half == 0) {
+#pragma unroll
+      for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[db][e] += xo[(db * 16 + e) * 64 + lane];
+    }
+    __syncthreads();
+  }
+  if (half == 0 && key < T) {
     bf16* kr = dK + (tok0 + key) * lddk + hkv * D;
     bf16* vr = dV + (tok0 + key) * lddv + hkv * D;
 #pragma unroll
@@ -590,14 +624,14 @@ extern "C" int sd_attn_bwd2(const void* q, const void* k, const void* v, const v
   }
   {
     SdProfScope prof2(SD_K_ATTN_BWD_DQ, 3.0 * B * Hq * (double)T * T * D, sq);  // S, dP (recomputed), dQ
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((T + 127) / 128, Hq, B), dim3(256), 0, sq, (const bf16*)q, (const bf16*)k,
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((T + 127) / 128, Hq, B), dim3(512), 0, sq, (const bf16*)q, (const bf16*)k,
                        (const bf16*)v, (const bf16*)d_o, lse, (const float*)delta, (bf16*)dq, kv_len, ldq, ldk, ldv, ldo,
                        lddq, T, Hq, Hkv, scale);
   }
   SD_CHECK_LAUNCH();
   {
     SdProfScope prof(SD_K_ATTN_BWD_DKV, 4.0 * B * Hq * (double)T * T * D, st);  // S, dP, dV, dK
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((T + 127) / 128, Hkv, B), dim3(256), 0, st, (const bf16*)q,
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((T + 127) / 128, Hkv, B), dim3(512), 0, st, (const bf16*)q,
                        (const bf16*)k, (const bf16*)v, (const bf16*)d_o, lse, (const float*)delta, (bf16*)dk, (bf16*)dv,
                        kv_len, ldq, ldk, ldv, ldo, lddk, lddv, T, Hq, Hkv, scale);
   }
