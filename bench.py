@@ -113,6 +113,9 @@ def main():
                     help="apply lm_head / top-K / loss to all B*T rows (default: only the rows the loss reads, as "
                          "DistillationTrainer.compute_loss does on training steps)")
     ap.add_argument("--phases", action="store_true", help="print the wall time of the phases of a step (stderr)")
+    ap.add_argument("--experiment-pipeline", action="store_true",
+                    help="MEASUREMENT ONLY (not the reported configuration): issue the NEXT step's teacher pass under this "
+                         "step's backward")
     ap.add_argument("--no-overlap", action="store_true", help="single stream everywhere (clean per-kernel profiles)")
     args = ap.parse_args()
 
@@ -164,6 +167,7 @@ def main():
         return ops.logsoftmax_topk(t_logits, args.top_k, VOCAB)                             # train.py:80-91
 
     phase_ev = []
+    pending = []
 
     def mark():  # 5 event records per step on the current stream (always on: the backward time feeds the JSON line)
         e = torch.cuda.Event(enable_timing=True)
@@ -178,7 +182,9 @@ def main():
         if not args.full_head:  # rows whose shifted label is not -100 (distillation_loss.py:31-45); one host sync
             rows, row_labels = ops.loss_rows(batch["labels"])
         with torch.no_grad():
-            if side is None or not overlap:
+            if args.experiment_pipeline and overlap and pending:
+                tv, ti = pending.pop()  # EXPERIMENT: issued on the side stream under the previous step's backward
+            elif side is None or not overlap:
                 tv, ti = teacher_topk(rows)
             else:  # the frozen teacher is independent of the student: run it on a second HIP stream
                 side.wait_stream(torch.cuda.current_stream())
@@ -195,6 +201,11 @@ def main():
         else:
             total, task, distill, teach = loss_fn.forward_rows(logits, row_labels, teacher_top_k_v=tv, teacher_top_k_i=ti)
         mark()
+        if args.experiment_pipeline and overlap and side is not None:
+            with torch.no_grad():
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    pending.append(teacher_topk(rows))
         total.backward()                                                                    # HF trainer.py:1961
         mark()
         return total, task, distill, teach

@@ -102,6 +102,21 @@ int sd_qknorm_rope_bwd2(const void* dqk, const void* qkv, const void* q_gain, co
                         const void* sin_tab, void* dqkv, void* dq_gain, void* dk_gain, int accumulate_dw, void* workspace,
                         int M, int T, int Hq, int Hkv, float eps, void* reduce_stream, void* event, void* stream);
 
+/* Deferred gain-gradient reduce: with dw == NULL (sd_rmsnorm_bwd2 / _slabs) or dq_gain == NULL (sd_qknorm_rope_bwd2)
+ * the per-workgroup partial sums stay in `workspace` -- [sd_rmsnorm_bwd_partial_rows(M,H)][H] fp32, or
+ * [sd_qknorm_rope_bwd_partial_rows(M,Hq,Hkv)][256] fp32 with the q gain in columns 0..127 and the k gain in
+ * 128..255 -- and up to 8 such column sums are finished by ONE sd_colsum_reduce_batch launch (a layer's four gain
+ * gradients: HF:59-64 weight of input_layernorm / post_attention_layernorm, HF:237-238 q_norm / k_norm).
+ * out[c] (bf16) = (accumulate ? out[c] : 0) + sum_r partials[r*stride + c], fixed summation order. */
+typedef struct {
+  const float* partials;
+  void* out;
+  int nb, H, stride, accumulate;
+} sd_colsum_problem;
+int sd_rmsnorm_bwd_partial_rows(int M, int H);
+int sd_qknorm_rope_bwd_partial_rows(int M, int Hq, int Hkv);
+int sd_colsum_reduce_batch(const sd_colsum_problem* problems_host, int n, void* stream);
+
 /* ---- per-head q/k RMSNorm (head_dim 128) then rotate-half RoPE (HF:252-257, 121-170).
  * qkv [M,(Hq+2Hkv)*128] -> qk_out [M,(Hq+Hkv)*128]; cos/sin tables bf16 [T,128]; token m has position m % T. */
 int sd_qknorm_rope_fwd(const void* qkv, const void* q_gain, const void* k_gain, const void* cos_tab,

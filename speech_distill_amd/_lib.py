@@ -34,6 +34,11 @@ class GemmProblem(C.Structure):
                 ("ldc", C.c_int64), ("M", C.c_int32), ("N", C.c_int32)]
 
 
+class ColsumProblem(C.Structure):
+    _fields_ = [("partials", C.c_void_p), ("out", C.c_void_p), ("nb", C.c_int32), ("H", C.c_int32),
+                ("stride", C.c_int32), ("accumulate", C.c_int32)]
+
+
 class Layer(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("wqkv", "wo", "wgu", "wdown", "q_gain", "k_gain", "ln1", "ln2")]
 
@@ -85,6 +90,9 @@ PROTOTYPES = {
     "sd_kdloss_fwd_rows": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _vp]),
     "sd_kdloss_bwd_rows": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _vp]),
     "sd_rows_scatter": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    "sd_rmsnorm_bwd_partial_rows": (_i, [_i, _i]),
+    "sd_qknorm_rope_bwd_partial_rows": (_i, [_i, _i, _i]),
+    "sd_colsum_reduce_batch": (_i, [_vp, _i, _vp]),
     "sd_sumsq_bf16": (_i, [_vp, _i64, _vp, _vp]),
     "sd_adamw_bf16": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _vp, _f, _vp]),
     "sd_prof_begin": (_i, []),

@@ -101,6 +101,34 @@ SD_DEV bf16x8 acc_frag(const f32x16& p, int s) {
 // row index (within a 32x32 accumulator tile) of register `reg` for lane half h
 SD_DEV int acc_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
 
+// Epilogue store of a wave's 32 x 128 output tile held as four TRANSPOSED 32x32 accumulators (lane r = l&31 owns output
+// ROW r; register e of block db is column db*32 + acc_row(e, h)).  Stored straight from the registers this is 16
+// 8-byte stores per lane at a row stride -- every wave-instruction touches 32 different 256-byte rows, and the store
+// ISSUE, not bandwidth, sets the time (~9k cycles per workgroup, MI355X_MICROARCH "attention epilogue store tail").
+// Instead the tile goes through a wave-private 8 KiB LDS image in the [row][128] swizzled layout of every other tile
+// and leaves as whole rows: 16 B per lane, four complete 256-byte rows per wave-instruction, 8 instructions.
+SD_DEV void store_tile_rows(char* img, const f32x16 (&acc)[4], float mul, bf16* g_row0, long ld, int rows_valid, int lane) {
+  const int r = lane & 31, h = lane >> 5;
+  const int swr = f_swz(r);
+#pragma unroll
+  for (int db = 0; db < 4; ++db)
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      bf16x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = (bf16)(acc[db][4 * g4 + e] * mul);
+      *(bf16x4*)(img + r * 256 + (((db * 4 + g4) ^ swr) << 4) + 8 * h) = v;
+    }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // one wave's LDS operations complete in order; keep the compiler's too
+  const int ch = lane & 15;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int row = 4 * i + (lane >> 4);
+    const bf16x8 v = *(const bf16x8*)(img + row * 256 + ((ch ^ f_swz(row)) << 4));
+    if (row < rows_valid) *(bf16x8*)(g_row0 + (long)row * ld + ch * 8) = v;
+  }
+}
+
 // ------------------------------------------------------------------------------------------ forward
 // grid (ceil(T/128), Hq, B), 512 threads.  Waves w and w+4 own the SAME 32 query rows q0 + 32(w&3) .. +31 and split
 // the K/V tiles between them (half = w>>2 takes tiles t = 2i + half): at B*T = 2048 tokens there are only 1 024
@@ -158,7 +186,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const bf16* __restrict__ 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // my half's tile i has landed; everybody is done reading the other stage
     asm volatile("" ::: "memory");
-    {
+    if ((2 * (i + 1) + half) * 64 < kv_hi) {  // wave-uniform; a tile nobody will read is not fetched (and not waited for)
       char* nx = ring + (cur_i ^ 1) * 2 * TILE;
       kd.issue((2 * (i + 1) + half) * 64, nx, w);
       vd.issue((2 * (i + 1) + half) * 64, nx + TILE, w);
@@ -251,19 +279,10 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const bf16* __restrict__ 
   }
   l += __shfl_xor(l, 32, 64);
   const float inv = 1.f / l;
-  if (q < T) {
-    bf16* orow = O + (tok0 + q) * ldo + hq * D;
-#pragma unroll
-    for (int db = 0; db < 4; ++db)
-#pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        bf16x4 v;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = (bf16)(o[db][4 * g4 + e] * inv);
-        *(bf16x4*)(orow + db * 32 + 8 * g4 + 4 * h) = v;
-      }
-    if (h == 0) LSE[((long)b * Hq + hq) * T + q] = m * scale + __logf(l);
-  }
+  // every lane of a row has the same `inv` only after the two column halves are combined: lanes r and r+32 hold the
+  // same row, and `l` was just summed over them, so scaling per lane before the transposing store is exact
+  store_tile_rows((char*)xo, o, inv, O + (tok0 + q0w) * ldo + hq * D, ldo, T - q0w, lane);
+  if (q < T && h == 0) LSE[((long)b * Hq + hq) * T + q] = m * scale + __logf(l);
 }
 
 // -------------------------------------------------------------------------- delta = rowsum(dO * O)
@@ -345,7 +364,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const bf16* __restrict
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // my half's tile i has landed; everybody is done reading the other stage
     asm volatile("" ::: "memory");
-    {
+    if ((2 * (i + 1) + half) * 64 < kv_hi) {  // wave-uniform; a tile nobody will read is not fetched (and not waited for)
       char* nx = ring + (cur_i ^ 1) * 2 * TILE;
       kd.issue((2 * (i + 1) + half) * 64, nx, w);
       vd.issue((2 * (i + 1) + half) * 64, nx + TILE, w);
@@ -393,18 +412,11 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const bf16* __restrict
   }
   __syncthreads();
   if (half == 1) return;
-  if (q < T) {
-    bf16* orow = dQ + (tok0 + q) * lddq + hq * D;
 #pragma unroll
-    for (int db = 0; db < 4; ++db)
+  for (int db = 0; db < 4; ++db)
 #pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        bf16x4 v;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = (bf16)((acc[db][4 * g4 + e] + xo[(db * 16 + 4 * g4 + e) * 64 + lane]) * scale);
-        *(bf16x4*)(orow + db * 32 + 8 * g4 + 4 * h) = v;
-      }
-  }
+    for (int e = 0; e < 16; ++e) acc[db][e] += xo[(db * 16 + e) * 64 + lane];
+  store_tile_rows((char*)xo, acc, scale, dQ + (tok0 + q0w) * lddq + hq * D, lddq, T - q0w, lane);
 }
 
 // -------------------------------------------------------------------------------------------- dK, dV
@@ -494,7 +506,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const bf16* __restric
     asm volatile("" ::: "memory");
     if (threadIdx.x < 128) stat[(buf ^ 1) * 128 + st_which * 64 + st_i] = pend_sv;
     pend_sv = load_stat(it + 2);
-    stage_it(it + 1, buf ^ 1);
+    if (it + 1 < nit) stage_it(it + 1, buf ^ 1);
     const char* qs = ring + buf * 2 * TILE;
     const char* dos = qs + TILE;
     const int qb0 = (qt0 + it % per_head) * 64 + 32 * half;
@@ -555,22 +567,9 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const bf16* __restric
     }
     __syncthreads();
   }
-  if (half == 0 && key < T) {
-    bf16* kr = dK + (tok0 + key) * lddk + hkv * D;
-    bf16* vr = dV + (tok0 + key) * lddv + hkv * D;
-#pragma unroll
-    for (int db = 0; db < 4; ++db)
-#pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        bf16x4 a, bb;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          a[e] = (bf16)(dk[db][4 * g4 + e] * scale);
-          bb[e] = (bf16)dv[db][4 * g4 + e];
-        }
-        *(bf16x4*)(kr + db * 32 + 8 * g4 + 4 * h) = a;
-        *(bf16x4*)(vr + db * 32 + 8 * g4 + 4 * h) = bb;
-      }
+  if (half == 0) {
+    store_tile_rows((char*)xo, dk, scale, dK + (tok0 + k0w) * lddk + hkv * D, lddk, T - k0w, lane);
+    store_tile_rows((char*)xo + 8192, dv, 1.f, dV + (tok0 + k0w) * lddv + hkv * D, lddv, T - k0w, lane);
   }
 }
 

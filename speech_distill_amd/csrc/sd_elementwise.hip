@@ -177,6 +177,44 @@ __global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* __restr
   }
 }
 
+// Up to 8 independent column sums in ONE launch (a layer's gain gradients: input norm, post-attention norm, q gain,
+// k gain -- four launches of ~5 us each otherwise).  Block -> problem by a prefix table of 32-column blocks.
+struct ColsumBatch {
+  sd_colsum_problem p[8];
+  int first_block[9];
+  int n;
+};
+__global__ __launch_bounds__(256) void colsum_reduce_batch_kernel(ColsumBatch b) {
+  __shared__ float red[8][32];
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < 8; ++i)
+    if (i < b.n && (int)blockIdx.x >= b.first_block[i]) pi = i;
+  const sd_colsum_problem q = b.p[pi];
+  const float* part = q.partials;
+  bf16* out = (bf16*)q.out;
+  const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  const int c = ((int)blockIdx.x - b.first_block[pi]) * 32 + cl;
+  float s = 0.f;
+  if (c < q.H) {
+    int r = rg;
+    for (; r + 56 < q.nb; r += 64) {
+      float t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = part[(long)(r + 8 * u) * q.stride + c];
+      s += ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+    }
+    for (; r < q.nb; r += 8) s += part[(long)r * q.stride + c];
+  }
+  red[rg][cl] = s;
+  __syncthreads();
+  if (rg == 0 && c < q.H) {
+    float t = ((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl])) + ((red[4][cl] + red[5][cl]) + (red[6][cl] + red[7][cl]));
+    if (q.accumulate) t += (float)out[c];
+    out[c] = (bf16)t;
+  }
+}
+
 // ---------------------------------------------------------------------------- q/k norm + RoPE (d=128)
 // A head vector of 128 bf16 is owned by 16 lanes (8 elements each); a wave does 4 heads per step.
 // rotate_half partner of element i is i^64  <->  lane j ^ 8 inside the 16-lane group.
@@ -436,6 +474,7 @@ static int rmsnorm_bwd_any(const void* dy, const float* dy_slabs, int nsplit, co
   if (nch <= 1) SD_RMS_BWD(1); else if (nch == 2) SD_RMS_BWD(2); else if (nch <= 4) SD_RMS_BWD(4); else SD_RMS_BWD(8);
 #undef SD_RMS_BWD
   SD_CHECK_LAUNCH();
+  if (!dw) return 0;  // partial sums stay in `workspace` ([sd_rmsnorm_bwd_partial_rows][H]); the caller reduces them
   hipStream_t rs = ST;
   if (reduce_stream && event) {
     rs = (hipStream_t)reduce_stream;
@@ -444,6 +483,32 @@ static int rmsnorm_bwd_any(const void* dy, const float* dy_slabs, int nsplit, co
   }
   hipLaunchKernelGGL(colsum_reduce_kernel, dim3((H + 31) / 32), dim3(256), 0, rs, (const float*)workspace, (bf16*)dw,
                      nb, H, H, accumulate_dw);
+  SD_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int sd_rmsnorm_bwd_partial_rows(int M, int H) {
+  (void)H;
+  int nb = (M + 3) / 4 < 512 ? (M + 3) / 4 : 512;
+  const int rpb = (M + nb - 1) / nb;
+  return (M + rpb - 1) / rpb;
+}
+
+extern "C" int sd_colsum_reduce_batch(const sd_colsum_problem* problems_host, int n, void* stream) {
+  if (n <= 0 || n > 8 || !problems_host) return SD_ERR_SHAPE;
+  ColsumBatch b;
+  b.n = n;
+  int blocks = 0;
+  for (int i = 0; i < n; ++i) {
+    const sd_colsum_problem& q = problems_host[i];
+    if (!q.partials || !q.out || q.nb <= 0 || q.H <= 0 || q.stride < q.H) return SD_ERR_SHAPE;
+    b.p[i] = q;
+    b.first_block[i] = blocks;
+    blocks += (q.H + 31) / 32;
+  }
+  for (int i = n; i < 9; ++i) b.first_block[i] = blocks;
+  for (int i = n; i < 8; ++i) b.p[i] = b.p[0];
+  hipLaunchKernelGGL(colsum_reduce_batch_kernel, dim3(blocks), dim3(256), 0, ST, b);
   SD_CHECK_LAUNCH();
   return 0;
 }
@@ -494,6 +559,11 @@ extern "C" int64_t sd_qknorm_rope_bwd_workspace_bytes(int M, int Hq, int Hkv) {
   return (int64_t)qk_bwd_blocks((long)M * (Hq + Hkv), &ipb) * 256 * 4;
 }
 
+extern "C" int sd_qknorm_rope_bwd_partial_rows(int M, int Hq, int Hkv) {
+  int ipb;
+  return qk_bwd_blocks((long)M * (Hq + Hkv), &ipb);
+}
+
 extern "C" int sd_qknorm_rope_bwd2(const void* dqk, const void* qkv, const void* q_gain, const void* k_gain,
                                    const void* cos_tab, const void* sin_tab, void* dqkv, void* dq_gain, void* dk_gain,
                                    int accumulate_dw, void* workspace, int M, int T, int Hq, int Hkv, float eps,
@@ -507,6 +577,7 @@ extern "C" int sd_qknorm_rope_bwd2(const void* dqk, const void* qkv, const void*
                      (float*)workspace, M, T, Hq, Hkv, eps, ipb);
   SD_CHECK_LAUNCH();
   // partial layout [nb][256]: columns 0..127 -> q gain, 128..255 -> k gain
+  if (!dq_gain || !dk_gain) return 0;  // left in `workspace` ([sd_qknorm_rope_bwd_partial_rows][256]) for the caller
   hipStream_t rs = ST;
   if (reduce_stream && event) {
     rs = (hipStream_t)reduce_stream;

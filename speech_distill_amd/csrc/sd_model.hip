@@ -53,7 +53,7 @@ LayerActs carve(const Sizes& s, char* p) {
 // partials reduced on the side stream exist twice, used by layer parity: the grouped dW launch of layer l runs on
 // the side stream under the dX chain of layer l-1, which writes the other set.
 struct BwdScratch {
-  char *dxa[2], *dxb[2], *dqkv[2], *dgu[2], *ws_norm2[2], *ws_qk[2];
+  char *dxa[2], *dxb[2], *dqkv[2], *dgu[2], *ws_norm2[2], *ws_qk[2], *ws_norm1[2];
   char *dxn, *dqk, *dao, *delta, *dact, *ws_norm, *ws_splitk;
   int64_t total, splitk_bytes;
   BwdScratch(const Sizes& s, char* p) {
@@ -65,6 +65,7 @@ struct BwdScratch {
       dgu[i] = p; p += s.gu;
       ws_norm2[i] = p; p += al(sd_rmsnorm_bwd_workspace_bytes(s.M, s.h));
       ws_qk[i] = p; p += al(sd_qknorm_rope_bwd_workspace_bytes(s.M, s.Hq, s.Hkv));
+      ws_norm1[i] = p; p += al(sd_rmsnorm_bwd_workspace_bytes(s.M, s.h));
     }
     dxn = p; p += s.x;
     dqk = p; p += s.qk;
@@ -252,8 +253,8 @@ extern "C" int sd_qwen3_backward_rows(const sd_qwen3_dims* d, const sd_qwen3_par
   char* xn_rows = xn_f + s.x;
   const int acc = accumulate ? 1 : 0;
 #define ACC(ptr) (acc ? (const void*)(ptr) : (const void*)nullptr)
-  // A/B switch for measurements: SD_OVERLAP_MASK bit0 lm_head dW, bit1 gain reduces, bit2 attention dQ, bit3 grouped per-layer dW (default all on)
-  static const int ovl = getenv("SD_OVERLAP_MASK") ? atoi(getenv("SD_OVERLAP_MASK")) : 15;
+  // A/B switch for measurements: SD_OVERLAP_MASK bit0 lm_head dW, bit1 gain reduces, bit2 attention dQ, bit3 grouped per-layer dW, bit4 batched per-layer gain reduce (default all on)
+  static const int ovl = getenv("SD_OVERLAP_MASK") ? atoi(getenv("SD_OVERLAP_MASK")) : 31;
   hipStream_t s1 = (hipStream_t)stream, s2 = (hipStream_t)side_stream;
   EventLease lease;
   if (s2 && !(lease.set = lease_events())) return SD_ERR_WORKSPACE;
@@ -298,6 +299,7 @@ extern "C" int sd_qwen3_backward_rows(const sd_qwen3_dims* d, const sd_qwen3_par
   // and only then is the finished layer reported to the caller.  SD_OVERLAP_MASK bit 3 = 0 keeps four separate GEMMs
   // launched as their inputs appear.
   const bool grouped = (ovl & 8) != 0;
+  const bool batch_gains = grouped && (ovl & 16) != 0;  // bit 4: one batched gain-gradient reduce per layer
   int pending = -1;  // layer whose grouped dW is in flight on the side stream
   for (int l = s.L - 1; l >= 0; --l) {
     const int P = l & 1;
@@ -325,8 +327,10 @@ extern "C" int sd_qwen3_backward_rows(const sd_qwen3_dims* d, const sd_qwen3_par
     RUN(sd_gemm_bf16_splitk_partial(dgu, w.wgu, b.dxn, s.M, s.h, 2 * s.I, 2 * s.I, s.h, s.h, 0, 1, b.ws_splitk,
                                     b.splitk_bytes, &nsp, stream));
     if (!grouped) RUN(sd_gemm_bf16(dgu, a.xn2, gw.wgu, ACC(gw.wgu), 2 * s.I, s.h, s.M, 2 * s.I, s.h, s.h, s.h, 1, 1, wstream));
-    NORM_BWD(a.x_mid, w.ln2, (const float*)a.rstd2, dx_in, dxb, gw.ln2, b.ws_norm2[P], (ovl & 2) ? side_stream : nullptr,
-             s2 ? (void*)g_ev[8] : nullptr);
+    // gain gradients of the layer: the kernels leave per-workgroup partial sums, ONE batched reduce finishes all four
+    // (input norm, post-attention norm, q gain, k gain) on the side stream once the layer's last kernel is enqueued
+    NORM_BWD(a.x_mid, w.ln2, (const float*)a.rstd2, dx_in, dxb, batch_gains ? nullptr : gw.ln2, b.ws_norm2[P],
+             (ovl & 2) ? side_stream : nullptr, s2 ? (void*)g_ev[8] : nullptr);
     if (!grouped) SIGNAL(2);  // dxb final
     // attention
     RUN(sd_gemm_bf16(dxb, w.wo, b.dao, nullptr, s.M, s.QD, s.h, s.h, s.QD, s.QD, 0, 0, 1, stream));
@@ -334,8 +338,9 @@ extern "C" int sd_qwen3_backward_rows(const sd_qwen3_dims* d, const sd_qwen3_par
     RUN(sd_attn_bwd2(a.qk, a.qk + (int64_t)s.QD * 2, a.qkv + (int64_t)(s.QD + s.KD) * 2, a.ao, b.dao, (const float*)a.lse,
                     (float*)b.delta, b.dqk, b.dqk + (int64_t)s.QD * 2, dqkv + (int64_t)(s.QD + s.KD) * 2, kv_len, s.QK,
                     s.QK, s.QKV, s.QD, s.QK, s.QK, s.QKV, B, T, s.Hq, s.Hkv, 128, scale, (ovl & 4) ? side_stream : nullptr, stream));
-    RUN(sd_qknorm_rope_bwd2(b.dqk, a.qkv, w.q_gain, w.k_gain, cos_tab, sin_tab, dqkv, gw.q_gain, gw.k_gain, acc, b.ws_qk[P],
-                            s.M, T, s.Hq, s.Hkv, d->eps, (ovl & 2) ? side_stream : nullptr, s2 ? (void*)g_ev[9] : nullptr, stream));
+    RUN(sd_qknorm_rope_bwd2(b.dqk, a.qkv, w.q_gain, w.k_gain, cos_tab, sin_tab, dqkv, batch_gains ? nullptr : gw.q_gain,
+                            batch_gains ? nullptr : gw.k_gain, acc, b.ws_qk[P], s.M, T, s.Hq, s.Hkv, d->eps,
+                            (ovl & 2) ? side_stream : nullptr, s2 ? (void*)g_ev[9] : nullptr, stream));
     SIGNAL(3);  // dqkv final (and with it dx_in, dgu, dxb of this layer)
     if (grouped) {
       sd_gemm_problem pr[4] = {
@@ -350,7 +355,7 @@ extern "C" int sd_qwen3_backward_rows(const sd_qwen3_dims* d, const sd_qwen3_par
       } else if (rc) {
         return rc;
       }
-      if (s2 && hipEventRecord(g_ev[10 + P], s2) != hipSuccess) return SD_ERR_WORKSPACE;
+      if (!batch_gains && s2 && hipEventRecord(g_ev[10 + P], s2) != hipSuccess) return SD_ERR_WORKSPACE;
     } else {
       RUN(sd_gemm_bf16(dqkv, a.xn1, gw.wqkv, ACC(gw.wqkv), s.QKV, s.h, s.M, s.QKV, s.h, s.h, s.h, 1, 1, wstream));
     }
@@ -362,7 +367,21 @@ extern "C" int sd_qwen3_backward_rows(const sd_qwen3_dims* d, const sd_qwen3_par
     } else {
       JOIN();  // the layer's dW GEMMs are done before their inputs are overwritten and before the callback
     }
-    NORM_BWD(a.x_in, w.ln1, (const float*)a.rstd1, dxb, dx_out, gw.ln1, b.ws_norm, nullptr, nullptr);
+    NORM_BWD(a.x_in, w.ln1, (const float*)a.rstd1, dxb, dx_out, batch_gains ? nullptr : gw.ln1,
+             batch_gains ? b.ws_norm1[P] : b.ws_norm, nullptr, nullptr);
+    if (batch_gains) {
+      // the side stream (after this layer's grouped dW) waits for the partials, reduces, and only then marks the
+      // layer finished: the event below now covers the weight AND the gain gradients of layer l
+      if (s2 && (hipEventRecord(g_ev[6], s1) != hipSuccess || hipStreamWaitEvent(s2, g_ev[6], 0) != hipSuccess))
+        return SD_ERR_WORKSPACE;
+      const int nb_n = sd_rmsnorm_bwd_partial_rows(s.M, s.h), nb_q = sd_qknorm_rope_bwd_partial_rows(s.M, s.Hq, s.Hkv);
+      const sd_colsum_problem cp[4] = {{(const float*)b.ws_norm2[P], gw.ln2, nb_n, s.h, s.h, acc},
+                                       {(const float*)b.ws_norm1[P], gw.ln1, nb_n, s.h, s.h, acc},
+                                       {(const float*)b.ws_qk[P], gw.q_gain, nb_q, 128, 256, acc},
+                                       {(const float*)b.ws_qk[P] + 128, gw.k_gain, nb_q, 128, 256, acc}};
+      RUN(sd_colsum_reduce_batch(cp, 4, wstream));
+      if (s2 && hipEventRecord(g_ev[10 + P], s2) != hipSuccess) return SD_ERR_WORKSPACE;
+    }
     if (grouped) {
       if (pending >= 0 && on_grads_ready) on_grads_ready(pending, cb_user);
       pending = l;

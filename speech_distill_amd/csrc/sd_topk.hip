@@ -5,7 +5,7 @@
 //     logits[..., :V] -> log_softmax (T=1) -> topk(K), sorted descending -> values fp16, indices int32
 // Selection is an exact MSB-first radix select on order-preserving integer keys of the raw logits
 // (log-softmax is monotone, so selecting on logits == selecting on log-probs); ties at the K-th
-// value go to the LOWEST indices.  One 1024-thread workgroup per row; the row is re-read from
+// value go to the LOWEST indices.  One 512-thread workgroup per row, two resident per CU; the row is re-read from
 // L2/Infinity Cache by the later radix passes, so HBM sees it about once.
 #include "sd_common.cuh"
 #include "../../include/sd_hip.h"
@@ -13,7 +13,7 @@
 
 namespace {
 
-constexpr int NT = 1024;
+constexpr int NT = 512;  // two workgroups per CU: one row's select/sort phases run beside another row's streaming read
 constexpr int KMAX = 1024;
 
 SD_DEV uint32_t f2key(float f) {
@@ -91,18 +91,18 @@ SD_DEV void bitonic_desc(unsigned long long* items, int P2) {
 }
 
 // Fast path.  Thread t's maximum over its own strided share of the row is one of the row's values, so
-// the K-th largest of the 1024 thread maxima (t0) is a lower bound of the row's K-th largest value:
+// the K-th largest of the NT thread maxima (t0) is a lower bound of the row's K-th largest value:
 // every top-K element has key >= t0, and for non-degenerate rows only ~K..2K elements do.  Those few
 // candidates are sorted exactly (value desc, index asc).  Rows with more than CAP candidates (massive
 // ties) take the general MSB-first radix select below.
 template <typename T, int NPASS>
-__global__ __launch_bounds__(NT) void topk_kernel(const T* __restrict__ X, _Float16* __restrict__ outv,
+__global__ __launch_bounds__(NT, 4) void topk_kernel(const T* __restrict__ X, _Float16* __restrict__ outv,
                                                   int32_t* __restrict__ outi, float* __restrict__ lse_out, int rows,
                                                   long row_stride, int V, int K, int KP) {
   __shared__ float sc[32];
   __shared__ int hist[256];
   __shared__ int sel_bin, sel_kth, n_out, tie_base;
-  __shared__ int wave_cnt[16];
+  __shared__ int wave_cnt[NT / 64];
   __shared__ uint32_t tkeys[NT];
   __shared__ unsigned long long items[CAP];
   const int row = blockIdx.x;
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(NT) void topk_kernel(const T* __restrict__ X, _Floa
       if (lane == 63) wave_cnt[wv] = incl;
       __syncthreads();
       int wbase = tie_base, tot = 0;
-      for (int w2 = 0; w2 < 16; ++w2) {
+      for (int w2 = 0; w2 < NT / 64; ++w2) {
         const int cw = wave_cnt[w2];
         if (w2 < wv) wbase += cw;
         tot += cw;
