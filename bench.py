@@ -255,6 +255,7 @@ def main():
         barrier()
         prof_dt = time.perf_counter() - tp
         prof = ops.prof_end()
+        syms = ops.prof_symbols()
         student.overlap_dw = not args.no_overlap
     if multi:
         tmax = torch.tensor([dt], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
@@ -313,29 +314,34 @@ def main():
             res["kernels"] = kinds
             res["kernel_ms_per_step_sum"] = tot_ms / args.steps
             res["profiled_pass_ms_per_step"] = 1e3 * prof_dt / args.steps
-            dom = max((k for k in prof if prof[k][2] > 0), key=lambda k: prof[k][0])
-            ms, work, cnt = prof[dom]
-            if dom.startswith(("gemm", "attn")):
-                ach = work / (ms * 1e-3) / 1e12
-                res["roofline"] = {"bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                   "frac": ach / MFMA_PEAK_TFLOPS, "traffic": None,
-                                   "measured": "HIP events on the launch stream, same K steps re-run right after the timed region",
-                                   "kernel": KERNEL_NAMES.get(dom, dom), "avg_launch_us": 1e3 * ms / cnt,
-                                   "launches_per_step": cnt / args.steps,
-                                   "algorithmic_flops_per_launch_avg": work / cnt}
-            else:
-                ach = work / (ms * 1e-3) / 1e9
-                res["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                   "frac": ach / HBM_PEAK_GBS, "traffic": None, "kernel": dom,
-                                   "avg_launch_us": 1e3 * ms / cnt, "launches_per_step": cnt / args.steps}
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+            # ONE dominant kernel symbol (named as rocprofv3 --kernel-trace prints it, a row of
+            # profiles/r02_bench_serial_kernel_stats.csv); the kind it belongs to is given beside it as `family`
+            dom = max(syms, key=lambda k: syms[k][0])
+            ms, work, cnt, kind = syms[dom]
+            fam_ms, fam_work, fam_cnt = prof[kind]
+            mfma = kind.startswith(("gemm", "attn"))
+            ach = work / (ms * 1e-3) / (1e12 if mfma else 1e9)
+            peak = MFMA_PEAK_TFLOPS if mfma else HBM_PEAK_GBS
+            res["roofline"] = {
+                "bound": "mfma" if mfma else "hbm", "achieved": ach, "peak": peak, "unit": "TFLOP/s" if mfma else "GB/s",
+                "frac": ach / peak, "traffic": None, "kernel": dom, "avg_launch_us": 1e3 * ms / cnt,
+                "launches_per_step": cnt / args.steps, "ms_per_step": ms / args.steps,
+                ("algorithmic_flops_per_launch_avg" if mfma else "algorithmic_bytes_per_launch_avg"): work / cnt,
+                "measured": "HIP events on the launch stream around every launch (sd_prof_*), the same K steps re-run "
+                            "on ONE stream right after the timed region",
+                "family": {"kind": kind, "kernels": KERNEL_NAMES.get(kind, kind), "ms_per_step": fam_ms / args.steps,
+                           "launches_per_step": fam_cnt / args.steps,
+                           "achieved": fam_work / (fam_ms * 1e-3) / (1e12 if mfma else 1e9)},
+                "by_symbol_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in
+                                          sorted(syms.items(), key=lambda kv: -kv[1][0])[:12]}}
+        pmc = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
         if "roofline" in res and os.path.exists(pmc):
             try:  # HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
                 t = json.load(open(pmc))
-                e = t.get(dom)
+                e = t.get("kernels", {}).get(res["roofline"]["kernel"])
                 if e is not None:
                     res["roofline"]["traffic"] = e["hbm_bytes_per_launch"]
-                    res["roofline"]["traffic_source"] = os.path.relpath(pmc, ROOT) + " (" + e["kernel"] + "): " + t["method"]
+                    res["roofline"]["traffic_source"] = os.path.relpath(pmc, ROOT) + ": " + t["method"]
             except Exception:
                 pass
         if world == 1 and not args.no_cpu_baseline:

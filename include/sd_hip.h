@@ -263,6 +263,9 @@ enum {
 };
 int sd_prof_begin(void);
 int sd_prof_end(double* ms, double* work, int64_t* count, int n_kinds);
+/* The same measurement per KERNEL SYMBOL (as rocprofv3 --kernel-trace names it, without namespace and arguments), as
+ * text lines "symbol<TAB>kind<TAB>ms<TAB>work<TAB>launches"; returns the bytes needed (cap = 0 sizes the buffer). */
+int64_t sd_prof_symbols(char* buf, int64_t cap);
 
 #ifdef __cplusplus
 }

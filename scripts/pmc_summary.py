@@ -1,4 +1,5 @@
-"""Turns the two rocprofv3 --pmc passes of scripts/profile_round.sh into profiles/<tag>_pmc_traffic.json:
+"""Turns the rocprofv3 --pmc passes of scripts/profile_round.sh into profiles/<tag>_pmc_traffic.json (mode `traffic`:
+every kernel symbol, with the GB/s it sustained) and profiles/<tag>_mfma_busy.json (mode `mfma`).  Legacy default mode:
 HBM bytes per launch of the dominant GEMM kernel (and of every NT GEMM), per MI355X_MICROARCH.md section HBM:
 counter unit KB, FETCH_SIZE doubled on gfx950 for 16-B/lane streaming reads.
 usage: python scripts/pmc_summary.py gpurun_out/prof_r01 profiles/r01_pmc_traffic.json"""
@@ -46,9 +47,85 @@ def mfma_busy(src, dst, n_cu=256):
     print(json.dumps({"whole_run": out["whole_run_mfma_busy_share"], "top": [(r["kernel"][:70], round(r["mfma_busy_share"], 3)) for r in rows[:12]]}, indent=1))
 
 
+def symbol(name):
+    """rocprofv3 kernel name -> the symbol bench.py reports: demangled, without `void`, namespace and argument list."""
+    m = re.match(r"_ZN12_GLOBAL__N_1(\d+)", name)
+    if m:  # rocprofv3 leaves names with __bf16 template arguments mangled (no demangler here knows DF16b): decode the
+        # simple forms our kernels use -- <name>I(Li<int>E | Lb<0|1>E | DF16b | f)*E
+        n = int(m.group(1))
+        base, rest = name[m.end():m.end() + n], name[m.end() + n:]
+        args = []
+        if rest.startswith("I"):
+            rest = rest[1:]
+            while rest and not rest.startswith("E"):
+                a = re.match(r"Li(\d+)E|Lb([01])E|(DF16b)|(f)", rest)
+                if not a:
+                    args = None
+                    break
+                args.append(a.group(1) if a.group(1) else ("true" if a.group(2) == "1" else "false") if a.group(2)
+                            else "__bf16" if a.group(3) else "float")
+                rest = rest[a.end():]
+        return base + ("<" + ", ".join(args) + ">" if args else "")
+    name = re.sub(r"^void ", "", name).replace("(anonymous namespace)::", "")
+    depth = 0
+    for i, ch in enumerate(name):  # cut at the '(' that opens the argument list (outside template brackets)
+        if ch == "<":
+            depth += 1
+        elif ch == ">":
+            depth -= 1
+        elif ch == "(" and depth == 0:
+            return name[:i]
+    return name
+
+
+def traffic_all(src, dst):
+    """Per kernel symbol: HBM-side bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, KB units) and, with the average
+    duration of the same kernel in the serial --kernel-trace pass, the HBM-side GB/s it sustained."""
+    fetch = per_kernel(src + "/fetch", "FETCH_SIZE")
+    write = per_kernel(src + "/write", "WRITE_SIZE")
+    dur = {}
+    for f in glob.glob(src + "/serial/**/*kernel_stats.csv", recursive=True):
+        for row in csv.DictReader(open(f)):
+            dur[symbol(row["Name"])] = (float(row["AverageNs"]) / 1e3, int(row["Calls"]))
+    agg = {}
+    for raw, (n, v) in fetch.items():
+        a = agg.setdefault(symbol(raw), {"launches": 0, "fetch": 0.0, "wl": 0, "write": 0.0})
+        a["launches"] += n
+        a["fetch"] += v * 1024.0 * 2.0
+    for raw, (n, v) in write.items():
+        a = agg.setdefault(symbol(raw), {"launches": 0, "fetch": 0.0, "wl": 0, "write": 0.0})
+        a["wl"] += n
+        a["write"] += v * 1024.0
+    kernels = {}
+    for sym, a in agg.items():
+        if not a["launches"] or not a["wl"] or sym.startswith(("at::", "rocprim", "__amd")):
+            continue
+        fb, wb = a["fetch"] / a["launches"], a["write"] / a["wl"]
+        e = {"launches": a["launches"], "fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb,
+             "hbm_bytes_per_launch": fb + wb}
+        if sym in dur:
+            e["avg_us_serial_trace"] = dur[sym][0]
+            e["hbm_gbs"] = (fb + wb) / dur[sym][0] / 1e3
+        kernels[sym] = e
+    out = {"method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over `python3 bench.py --steps 2 "
+                     "--warmup 1 --no-cpu-baseline --no-prof --no-overlap` (scripts/profile_round.sh); counter unit KB; "
+                     "FETCH_SIZE doubled (gfx950 reports half the bytes of 16-B/lane streaming reads, "
+                     "MI355X_MICROARCH.md section HBM; other access widths are uncalibrated); per-launch averages over "
+                     "all launches of the kernel; avg_us_serial_trace / hbm_gbs use the same kernel's average duration "
+                     "in the --kernel-trace --stats pass of the same command (profiles/<tag>_bench_serial_kernel_stats.csv). "
+                     "These are memory-side (fabric) bytes: Infinity-Cache hits are counted, not excluded",
+           "kernels": dict(sorted(kernels.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"]))}
+    json.dump(out, open(dst, "w"), indent=1)
+    for k in list(out["kernels"])[:25]:
+        e = out["kernels"][k]
+        print(f"{k[:60]:60s} n={e['launches']:5d} {e['hbm_bytes_per_launch'] / 1e6:9.2f} MB/launch  {e.get('avg_us_serial_trace', 0):8.1f} us  {e.get('hbm_gbs', 0):7.0f} GB/s")
+
+
 def main():
     if len(sys.argv) > 3 and sys.argv[3] == "mfma":
         return mfma_busy(sys.argv[1], sys.argv[2])
+    if len(sys.argv) > 3 and sys.argv[3] == "traffic":
+        return traffic_all(sys.argv[1], sys.argv[2])
     src, dst = sys.argv[1], sys.argv[2]
     fetch = per_kernel(src + "/fetch", "FETCH_SIZE")
     write = per_kernel(src + "/write", "WRITE_SIZE")

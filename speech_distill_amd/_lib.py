@@ -97,6 +97,7 @@ PROTOTYPES = {
     "sd_adamw_bf16": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _vp, _f, _vp]),
     "sd_prof_begin": (_i, []),
     "sd_prof_end": (_i, [_vp, _vp, _vp, _i]),
+    "sd_prof_symbols": (_i64, [_vp, _i64]),
     "sd_qwen3_acts_bytes": (_i64, [C.POINTER(Dims), _i, _i, _i]),
     "sd_qwen3_bwd_scratch_bytes": (_i64, [C.POINTER(Dims), _i, _i]),
     "sd_qwen3_forward": (_i, [C.POINTER(Dims), C.POINTER(Params), _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i, _i, _i, _vp]),

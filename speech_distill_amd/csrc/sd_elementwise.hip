@@ -434,6 +434,7 @@ extern "C" int sd_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd
   if (M <= 0 || (H & 7)) return SD_ERR_SHAPE;
   if (H > 4096) return SD_ERR_UNSUPPORTED;
   SdProfScope prof(SD_K_RMSNORM, 4.0 * M * H, ST);
+  SD_PROF_LABEL("rmsnorm_fwd_kernel<%d>", (H + 511) / 512 <= 1 ? 1 : (H + 511) / 512 == 2 ? 2 : (H + 511) / 512 <= 4 ? 4 : 8);
 #define SD_RMS_FWD(N) hipLaunchKernelGGL(rmsnorm_fwd_kernel<N>, dim3((M + 3) / 4), dim3(256), 0, ST, (const bf16*)x, \
                                          (const bf16*)w, (bf16*)y, rstd, M, H, eps)
   const int nch = (H + 511) / 512;
@@ -459,6 +460,7 @@ static int rmsnorm_bwd_any(const void* dy, const float* dy_slabs, int nsplit, co
   const int rpb = (M + nb - 1) / nb;
   nb = (M + rpb - 1) / rpb;
   SdProfScope prof(SD_K_RMSNORM, ((dres ? 8.0 : 6.0) + (dy_slabs ? 4.0 * nsplit - 2.0 : 0.0)) * M * H, ST);
+  SD_PROF_LABEL("rmsnorm_bwd_kernel<%d, %s>", (H + 511) / 512 <= 1 ? 1 : (H + 511) / 512 == 2 ? 2 : (H + 511) / 512 <= 4 ? 4 : 8, dy_slabs ? "true" : "false");
 #define SD_RMS_BWD(N)                                                                                                  \
   do {                                                                                                                 \
     if (dy_slabs)                                                                                                      \
@@ -539,6 +541,7 @@ extern "C" int sd_qknorm_rope_fwd(const void* qkv, const void* q_gain, const voi
   if (M <= 0 || T <= 0 || (M % T)) return SD_ERR_SHAPE;
   const long items = (long)M * (Hq + Hkv);
   SdProfScope prof(SD_K_QKROPE, 4.0 * items * 128, ST);
+  SD_PROF_LABEL("qknorm_rope_fwd_kernel");
   hipLaunchKernelGGL(qknorm_rope_fwd_kernel, dim3((unsigned)((items + 15) / 16)), dim3(256), 0, ST, (const bf16*)qkv,
                      (const bf16*)q_gain, (const bf16*)k_gain, (const bf16*)cos_tab, (const bf16*)sin_tab, (bf16*)qk_out,
                      M, T, Hq, Hkv, eps);
@@ -572,6 +575,7 @@ extern "C" int sd_qknorm_rope_bwd2(const void* dqk, const void* qkv, const void*
   int ipb;
   const int nb = qk_bwd_blocks((long)M * (Hq + Hkv), &ipb);
   SdProfScope prof(SD_K_QKROPE, 6.0 * M * (Hq + Hkv) * 128, ST);
+  SD_PROF_LABEL("qknorm_rope_bwd_kernel");
   hipLaunchKernelGGL(qknorm_rope_bwd_kernel, dim3(nb), dim3(256), 0, ST, (const bf16*)dqk, (const bf16*)qkv,
                      (const bf16*)q_gain, (const bf16*)k_gain, (const bf16*)cos_tab, (const bf16*)sin_tab, (bf16*)dqkv,
                      (float*)workspace, M, T, Hq, Hkv, eps, ipb);
@@ -606,6 +610,7 @@ extern "C" int sd_swiglu_fwd(const void* gate_up, void* act, int M, int I, void*
   const long n8 = (long)M * I / 8;
   const int nb = (int)((n8 + 255) / 256 < 4096 ? (n8 + 255) / 256 : 4096);
   SdProfScope prof(SD_K_SWIGLU, 6.0 * M * I, ST);
+  SD_PROF_LABEL("swiglu_fwd_kernel");
   hipLaunchKernelGGL(swiglu_fwd_kernel, dim3(nb), dim3(256), 0, ST, (const bf16*)gate_up, (bf16*)act, n8, I);
   SD_CHECK_LAUNCH();
   return 0;
@@ -616,6 +621,7 @@ extern "C" int sd_swiglu_bwd(const void* dact, const void* gate_up, void* dgate_
   const long n8 = (long)M * I / 8;
   const int nb = (int)((n8 + 255) / 256 < 4096 ? (n8 + 255) / 256 : 4096);
   SdProfScope prof(SD_K_SWIGLU, 10.0 * M * I, ST);
+  SD_PROF_LABEL("swiglu_bwd_kernel");
   hipLaunchKernelGGL(swiglu_bwd_kernel, dim3(nb), dim3(256), 0, ST, (const bf16*)dact, (const bf16*)gate_up,
                      (bf16*)dgate_up, n8, I);
   SD_CHECK_LAUNCH();

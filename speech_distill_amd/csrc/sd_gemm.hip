@@ -1122,6 +1122,7 @@ int launch(const void* A, const void* B, void* C, const void* R, float* slabs, i
   do {                                                                                                               \
     if constexpr (BM == 256 && NST == 9 && (EPI == 0 || EPI == 3)) {                                                 \
       if (splits == 1 && tiles_m * tiles_n > persist_grid && persist_grid > 0) {                                       \
+        SD_PROF_LABEL("gemm_pstag_kernel<4, %s, %s, %d>", TA ? "true" : "false", TB ? "true" : "false", EPI);          \
         hipLaunchKernelGGL((gemm_pstag_kernel<4, TA, TB, EPI>), dim3(persist_grid), dim3(768), 0, st, (const bf16*)A,  \
                            (const bf16*)B, (bf16*)C, (const bf16*)R, M, N, K, lda, ldb, ldc, ldr, tiles_m, tiles_n,    \
                            gm, ea);                                                                                    \
@@ -1129,17 +1130,21 @@ int launch(const void* A, const void* B, void* C, const void* R, float* slabs, i
       }                                                                                                                \
     }                                                                                                                  \
     if constexpr (BM == 256 && NST == 9) {                                                                           \
+      SD_PROF_LABEL("gemm_stag_kernel<%s, %s, %d>", TA ? "true" : "false", TB ? "true" : "false", EPI);                \
       hipLaunchKernelGGL((gemm_stag_kernel<TA, TB, EPI>), grid, block, 0, st, (const bf16*)A, (const bf16*)B,          \
                          (bf16*)C, (const bf16*)R, slabs, M, N, K, lda, ldb, ldc, ldr, tiles_m, tiles_n, per, gm, ea); \
     } else if constexpr (BM == 64 && NST == 9) {                                                                     \
+      SD_PROF_LABEL("gemm_ks_kernel<%s, %s, %d>", TA ? "true" : "false", TB ? "true" : "false", (EPI >= 3 ? 0 : EPI)); \
       hipLaunchKernelGGL((gemm_ks_kernel<TA, TB, (EPI >= 3 ? 0 : EPI)>), grid, block, 0, st, (const bf16*)A,           \
                          (const bf16*)B, (bf16*)C, (const bf16*)R, slabs, M, N, K, lda, ldb, ldc, ldr, tiles_m,        \
                          tiles_n, per, gm, ea);                                                                      \
-    } else if (fast || EPI >= 3)                                                                                     \
+    } else if (fast || EPI >= 3) {                                                                                   \
+      SD_PROF_LABEL("gemm_bf16_kernel<%d, %d, %s, %s, %d, true>", BM, (NST == 9 ? 3 : NST), TA ? "true" : "false",     \
+                    TB ? "true" : "false", EPI);                                                                       \
       hipLaunchKernelGGL((gemm_bf16_kernel<BM, (NST == 9 ? 3 : NST), TA, TB, EPI, true>), grid, block, 0, st,          \
                          (const bf16*)A, (const bf16*)B, (bf16*)C, (const bf16*)R, slabs, M, N, K, lda, ldb, ldc, ldr, \
                          tiles_m, tiles_n, per, gm, ea);                                                             \
-    else                                                                                                             \
+    } else                                                                                                           \
       hipLaunchKernelGGL((gemm_bf16_kernel<BM, (NST == 9 ? 3 : NST), TA, TB, (EPI >= 3 ? 0 : EPI), false>), grid,      \
                          block, 0, st, (const bf16*)A, (const bf16*)B, (bf16*)C, (const bf16*)R, slabs, M, N, K, lda,  \
                          ldb, ldc, ldr, tiles_m, tiles_n, per, gm, ea);                                              \
@@ -1334,6 +1339,7 @@ extern "C" int sd_gemm_grouped_tn(const sd_gemm_problem* probs, int n, int K, in
   cus &= ~7;
   if (cus <= 0) return SD_ERR_UNSUPPORTED;
   SdProfScope prof(SD_K_GEMM_TN, flops, (hipStream_t)stream);
+  SD_PROF_LABEL("gemm_pgroup_tn_kernel<%s>", accumulate ? "true" : "false");
   if (accumulate)
     hipLaunchKernelGGL(gemm_pgroup_tn_kernel<true>, dim3(start < cus ? start : cus), dim3(768), 0, (hipStream_t)stream, ga,
                        K, 4);

@@ -283,6 +283,7 @@ int run_fwd(const void* S, const void* Tl, const void* topv, const void* topi, c
             void* stats, float* out, int B, int Tlen, int V, int K, float temperature, float alpha, hipStream_t st) {
   const int rows = Tlen ? B * Tlen : B;  // Tlen == 0: B pre-selected rows
   SdProfScope prof(SD_K_LOSS_FWD, (double)rows * V * sizeof(T) * (Tl ? 2 : 1), st);
+  SD_PROF_LABEL("kd_fwd_kernel<%s>", sizeof(T) == 2 ? "__bf16" : "float");
   hipLaunchKernelGGL((kd_fwd_kernel<T>), dim3(rows), dim3(NT), 0, st, (const T*)S, (const T*)Tl, (const _Float16*)topv,
                      (const int32_t*)topi, labels, mask, (RowStats*)stats, rows, Tlen, V, K, temperature);
   SD_CHECK_LAUNCH();
@@ -298,6 +299,7 @@ int run_bwd(const void* S, const void* Tl, const void* topv, const void* topi, c
             hipStream_t st) {
   const int rows = Tlen ? B * Tlen : B;
   SdProfScope prof(SD_K_LOSS_BWD, (double)rows * V * sizeof(T) * (Tl ? 3 : 2), st);
+  SD_PROF_LABEL("kd_bwd_kernel<%s>", sizeof(T) == 2 ? "__bf16" : "float");
   hipLaunchKernelGGL((kd_bwd_kernel<T>), dim3(rows), dim3(NT), 0, st, (const T*)S, (const T*)Tl, (const _Float16*)topv,
                      (const int32_t*)topi, labels, (const RowStats*)stats, out, go, (T*)G, rows, Tlen, V, K, temperature,
                      alpha);

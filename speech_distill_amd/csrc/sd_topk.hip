@@ -7,13 +7,13 @@
 // (log-softmax is monotone, so selecting on logits == selecting on log-probs); ties at the K-th
 // value go to the LOWEST indices.  One 512-thread workgroup per row, two resident per CU; the row is re-read from
 // L2/Infinity Cache by the later radix passes, so HBM sees it about once.
+#include <stdlib.h>
 #include "sd_common.cuh"
 #include "../../include/sd_hip.h"
 #include "sd_prof.h"
 
 namespace {
 
-constexpr int NT = 512;  // two workgroups per CU: one row's select/sort phases run beside another row's streaming read
 constexpr int KMAX = 1024;
 
 SD_DEV uint32_t f2key(float f) {
@@ -75,6 +75,7 @@ SD_DEV void pick_bin(const int* hist, int kth, int* sel_bin, int* sel_kth) {
 constexpr int CAP = 2048;  // candidate capacity of the fast path
 
 // descending bitonic sort of items[0..P2) (P2 a power of two), all NT threads participate
+template <int NT>
 SD_DEV void bitonic_desc(unsigned long long* items, int P2) {
   for (int size = 2; size <= P2; size <<= 1) {
     for (int stride = size >> 1; stride > 0; stride >>= 1) {
@@ -95,8 +96,13 @@ SD_DEV void bitonic_desc(unsigned long long* items, int P2) {
 // every top-K element has key >= t0, and for non-degenerate rows only ~K..2K elements do.  Those few
 // candidates are sorted exactly (value desc, index asc).  Rows with more than CAP candidates (massive
 // ties) take the general MSB-first radix select below.
-template <typename T, int NPASS>
-__global__ __launch_bounds__(NT, 4) void topk_kernel(const T* __restrict__ X, _Float16* __restrict__ outv,
+// NT threads per row: several workgroups are resident per CU (NT = 512: 4), so one row's select / sort phases (all
+// barriers, no memory traffic) run beside other rows' streaming reads (1024 threads, one workgroup per CU: 259 us at
+// R = 1536, V = 159 488; 512 or 256 threads: 195 us).  Measured and dropped: keeping every thread's 4 largest items in
+// registers during the first read so that the row is read once (the insertion test fires in some lane of every wave
+// for every chunk at 39 chunks per thread: 247 us).
+template <typename T, int NPASS, int NT>
+__global__ __launch_bounds__(NT) void topk_kernel(const T* __restrict__ X, _Float16* __restrict__ outv,
                                                   int32_t* __restrict__ outi, float* __restrict__ lse_out, int rows,
                                                   long row_stride, int V, int K, int KP) {
   __shared__ float sc[32];
@@ -252,7 +258,7 @@ __global__ __launch_bounds__(NT, 4) void topk_kernel(const T* __restrict__ X, _F
       if (i >= n_out || i >= K) items[i] = 0ull;
     __syncthreads();
   }
-  bitonic_desc(items, P2);
+  bitonic_desc<NT>(items, P2);
   for (int i = threadIdx.x; i < K; i += NT) {
     const unsigned long long it = items[i];
     const float val = key2f((uint32_t)(it >> 32));
@@ -271,14 +277,20 @@ extern "C" int sd_logsoftmax_topk(const void* logits, void* top_v, void* top_i, 
   while (KP < K) KP <<= 1;
   hipStream_t st = (hipStream_t)stream;
   SdProfScope prof(SD_K_TOPK, (double)rows * V * (dtype == SD_DTYPE_BF16 ? 2 : 4), st);
-  if (dtype == SD_DTYPE_BF16)
-    hipLaunchKernelGGL((topk_kernel<bf16, 2>), dim3(rows), dim3(NT), 0, st, (const bf16*)logits, (_Float16*)top_v,
-                       (int32_t*)top_i, lse_out, rows, (long)row_stride, V, K, KP);
-  else if (dtype == SD_DTYPE_F32)
-    hipLaunchKernelGGL((topk_kernel<float, 4>), dim3(rows), dim3(NT), 0, st, (const float*)logits, (_Float16*)top_v,
-                       (int32_t*)top_i, lse_out, rows, (long)row_stride, V, K, KP);
-  else
+  static const int nt_env = getenv("SD_TOPK_NT") ? atoi(getenv("SD_TOPK_NT")) : 0;  // A/B measurements
+  const int nt = (nt_env == 256 || nt_env == 512 || nt_env == 1024) ? nt_env : 512;
+#define SD_TOPK_GO(T_, NP_, NT_)                                                                                     \
+  SD_PROF_LABEL("topk_kernel<%s, %d, %d>", sizeof(T_) == 2 ? "__bf16" : "float", NP_, NT_);                          \
+  hipLaunchKernelGGL((topk_kernel<T_, NP_, NT_>), dim3(rows), dim3(NT_), 0, st, (const T_*)logits, (_Float16*)top_v, \
+                     (int32_t*)top_i, lse_out, rows, (long)row_stride, V, K, KP)
+  if (dtype == SD_DTYPE_BF16) {
+    if (nt == 256) { SD_TOPK_GO(bf16, 2, 256); } else if (nt == 1024) { SD_TOPK_GO(bf16, 2, 1024); } else { SD_TOPK_GO(bf16, 2, 512); }
+  } else if (dtype == SD_DTYPE_F32) {
+    if (nt == 256) { SD_TOPK_GO(float, 4, 256); } else if (nt == 1024) { SD_TOPK_GO(float, 4, 1024); } else { SD_TOPK_GO(float, 4, 512); }
+  } else {
     return SD_ERR_UNSUPPORTED;
+  }
+#undef SD_TOPK_GO
   SD_CHECK_LAUNCH();
   return 0;
 }

@@ -384,6 +384,21 @@ def prof_end():
     return {KINDS[i]: (ms[i], work[i], cnt[i]) for i in range(n)}
 
 
+def prof_symbols():
+    """-> {kernel symbol: (total_ms, total_work, launches, kind)} of the last prof_end (see sd_prof_symbols)."""
+    import ctypes as C
+    from ._lib import KINDS
+    lib = load_lib()
+    n = lib.sd_prof_symbols(None, 0)
+    buf = C.create_string_buffer(int(n))
+    lib.sd_prof_symbols(buf, n)
+    out = {}
+    for line in buf.value.decode().splitlines():
+        sym, kind, ms, work, cnt = line.split("\t")
+        out[sym] = (float(ms), float(work), int(cnt), KINDS[int(kind)] if int(kind) < len(KINDS) else "?")
+    return out
+
+
 def rmsnorm_bwd_from_splitk(a, b_kn, x, w, rstd, dres=None):
     """dx, dw of RMSNorm where dy = a @ b_kn is produced by a split-K GEMM whose fp32 slabs the norm kernel sums
     itself (sd_gemm_bf16_splitk_partial + sd_rmsnorm_bwd_slabs).  Returns (dx, dw, nsplit)."""
