@@ -758,6 +758,206 @@ __global__ __launch_bounds__(768) void gemm_pstag_kernel(const bf16* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Persistent 256 x 256 kernel for the forward (NT) GEMMs with many output columns: lm_head (N = vocabulary) and gate|up.
+// Every kernel above is bound by the L2 -> LDS rate (one CU's LDS-DMA sustains ~59 GB/s), i.e. by FLOP per staged
+// byte, i.e. by tile area: 256 x 128 stages (256+128)*2 B per 2*256*128 FLOP of a k (85 FLOP/B, 0.81 us per 64-deep
+// K-step, 1.3 PFLOP/s in the loop); 256 x 256 stages 128 FLOP/B -- the same bytes per CU and K-step as 1.33 tiles of
+// 256 x 128 for twice the FLOPs.  The price is registers: a wave owns 64 x 128 of C = 128 accumulator registers, so
+// there are 8 waves (two per SIMD, 256 registers each) and no producer waves: the two 4-wave halves run the
+// staggered LOAD / COMPUTE protocol of gemm_stag_kernel and issue their own LDS-DMA.  LDS cannot hold three 64-deep
+// stages of a 256 x 256 tile (3 x 64 KiB), so the ring is NST = 4 stages of BK = 32 (32 KiB each, image rows of
+// 64 B = 4 chunks, XOR-swizzled by swz32(row)), three K-steps in flight; a phase is still 32 MFMAs per wave.
+//   LOAD(g):    issue A of K-step g+3 -> stage (g+3)%4 | ds_read K-step g | vmcnt(3*NI): my pieces of g+1 landed | lgkmcnt(0)
+//   COMPUTE(g): issue B of K-step g+3 | 32 x v_mfma_f32_16x16x32_bf16
+// Hazards as gemm_stag_kernel with NST = DEPTH + 1: RAW K-step x is first read in phase 2x, retired by every wave's
+// counted vmcnt at the end of its LOAD(x-1) and a barrier; WAR the stage of K-step x-1 is refilled from phase 2x on,
+// its last reads completed (lgkmcnt(0)) before the closing barriers of phases 2x-2 / 2x-1.
+// A workgroup walks its tiles as ONE K stream (the tile origin is a scalar offset of the buffer load); a finished
+// 16 x 64 block leaves through the wave's 2 KiB LDS patch as whole 128-byte lines.
+//   EPI 0: C = A.B^T     EPI 3: SwiGLU, B tile = 128 gate rows | 128 up rows: gate and up of one output sit in one lane.
+constexpr int P2_BK = 32;
+// chunk XOR of image row r: ds_read_b128 serves lanes in the groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ... (rows
+// {0-3,12-15} at k-chunk c with rows {4-11} at c^1): with g(r>>2) = 0,3,2,1 the 16 lanes of every group fall on 16
+// different 16-byte slots of the 256-byte bank row (the plain (r>>2)&3 gives 2-way conflicts: 0.9 instead of 0.5 us
+// per K-step).
+SD_DEV int swz32(int r) { return (0 - (r >> 2)) & 3; }
+SD_DEV bf16x8 load_frag32(const char* tile, int row16_base, int lane) {  // 16 rows x 32 k: lane l = row l&15, k 8(l>>4)..
+  const int r = row16_base + (lane & 15), c = lane >> 4;
+  return *(const bf16x8*)(tile + r * 64 + ((c ^ swz32(r)) << 4));
+}
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_p256_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B, bf16* C, int M,
+                                                        int N, int K, long lda, long ldb, long ldc, int tiles_m,
+                                                        int tiles_n, int group_m, EpiArgs ea) {
+  static_assert(EPI == 0 || EPI == 3, "plain or SwiGLU epilogue");
+  constexpr int BM = 256, BNN = 256, NW = 8, NST = 4, DEPTH = NST - 1;
+  constexpr int A_BYTES = BM * P2_BK * 2, STAGE = (BM + BNN) * P2_BK * 2;  // 16 / 32 KiB
+  constexpr int NI = BM * P2_BK * 2 / 1024 / NW;                           // 2 pieces of A and 2 of B per wave and K-step
+  constexpr int LOADS = 2 * NI;
+  constexpr int PATCH = 2048;
+  __shared__ __attribute__((aligned(16))) char smem[NST * STAGE + NW * PATCH];  // 144 KiB
+  const int lane = lane_id();
+  const int w = wave_id_uniform();
+  const int wm = w >> 1, wn = w & 1, half = w >> 2;
+  const int ntiles = tiles_m * tiles_n;
+  const int nk = K / P2_BK;
+  const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int total = my_tiles * nk;
+  auto origin = [&](int idx, int& tm, int& tn) {
+    const int t = xcd_remap((int)blockIdx.x + idx * (int)gridDim.x, ntiles);
+    tile_coords(t, tiles_m, tiles_n, group_m, tm, tn);
+  };
+  // ---- LDS-DMA of this wave: loop-invariant per-lane offsets, the tile origin and k are scalar
+  int voff_a[NI], voff_b[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int p = (w * NI + i) * 64 + lane;
+    const int r = p >> 2, c = (p & 3) ^ swz32(r);
+    voff_a[i] = (int)(((long)r * lda + c * 8) * 2);
+    voff_b[i] = (int)(((long)(r + ((EPI == 3 && r >= 128) ? ea.I - 128 : 0)) * ldb + c * 8) * 2);
+  }
+#if defined(__HIP_DEVICE_COMPILE__)
+  const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)(((long)(M - 1) * lda + K) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, (int)(((long)(N - 1) * ldb + K) * 2), 0x00020000);
+#endif
+  int pf_tile = 0, pf_k = 0;
+  unsigned pf_a = 0, pf_b = 0;
+  auto pf_set = [&](int idx) {
+    int tm = 0, tn = 0;
+    if (idx < my_tiles) origin(idx, tm, tn);
+    pf_a = (unsigned)((long)tm * BM * lda * 2);
+    pf_b = (unsigned)((long)tn * (EPI == 3 ? 128 : BNN) * ldb * 2);
+  };
+  // one K-step = A pieces (issued in the wave's LOAD phase) + B pieces (issued at the head of its COMPUTE phase, so that
+  // a LOAD phase -- which the other half's 512 cycles of MFMA have to cover -- carries 2 DMA issues + 12 LDS reads and
+  // not 4 + 12).  K-steps past the end re-read the first origin and are never used.
+  auto pf_issue_a = [&](char* stage) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int sa = (int)(pf_a + (unsigned)(pf_k * P2_BK * 2));
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (SD_LDS void*)(stage + (w * NI + i) * 1024), 16, voff_a[i], sa, 0, 0);
+#endif
+  };
+  auto pf_issue_b = [&](char* stage) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int sb = (int)(pf_b + (unsigned)(pf_k * P2_BK * 2));
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (SD_LDS void*)(stage + A_BYTES + (w * NI + i) * 1024), 16, voff_b[i], sb, 0, 0);
+#endif
+    if (++pf_k == nk) { pf_k = 0; pf_set(++pf_tile); }
+  };
+  pf_set(0);
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) { pf_issue_a(smem + d * STAGE); pf_issue_b(smem + d * STAGE); }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  if (half == 1) __builtin_amdgcn_s_barrier();  // second half runs one phase behind
+
+  f32x4 acc[4][8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  char* ep = smem + NST * STAGE + w * PATCH;
+  // a: 16 rows x 64 columns of this wave (4 fragments) -> dst rows gm0.., columns gn0.. as whole 128-byte lines
+  auto store_rows = [&](const bf16x4 (&o)[4], bf16* dst, long ldd, int gm0, int gn0, int nlim) {
+    const int r = lane & 15, q4 = lane >> 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) *(bf16x4*)(ep + r * 128 + (((2 * j + (q4 >> 1)) ^ (r & 7)) << 4) + (q4 & 1) * 8) = o[j];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const int rr = hh * 8 + (lane >> 3), cc = lane & 7;
+      const bf16x8 v = *(const bf16x8*)(ep + rr * 128 + ((cc ^ (rr & 7)) << 4));
+      const int gmr = gm0 + rr, gn = gn0 + cc * 8;
+      if (gmr < M && gn < nlim) *(bf16x8*)(dst + (long)gmr * ldd + gn) = v;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the patch is rewritten by the next block
+  };
+  int cur_i = 0, nxt_i = DEPTH, ck = 0, ctile = 0;
+  for (int g = 0; g < total; ++g) {
+    // ---- LOAD(g)
+    pf_issue_a(smem + nxt_i * STAGE);
+    const char* cur = smem + cur_i * STAGE;
+    bf16x8 af[4], bfr[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) af[i] = load_frag32(cur, wm * 64 + i * 16, lane);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int brow = (EPI == 3) ? (j >> 2) * 128 + wn * 64 + (j & 3) * 16 : wn * 128 + j * 16;
+      bfr[j] = load_frag32(cur + A_BYTES, brow, lane);
+    }
+    // issued so far, youngest first: A(g+3), B(g+2), A(g+2), B(g+1), ...: K-step g+1 has landed when all but 3*NI are done
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NI) : "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- COMPUTE(g)
+    pf_issue_b(smem + nxt_i * STAGE);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[i][j] = mfma16(bfr[j], af[i], acc[i][j]);
+    __builtin_amdgcn_s_setprio(0);
+    if (++ck == nk) {  // tile finished: this wave's 64 x 128 block leaves, clear, go on with the next tile
+      ck = 0;
+      int tm, tn;
+      origin(ctile++, tm, tn);
+      const int m0 = tm * BM;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int gm0 = m0 + wm * 64 + i * 16;
+        if constexpr (EPI == 3) {
+          // act columns tn*128 + wn*64 .. +63: gate in acc[i][0..3], up in acc[i][4..7] (same lane, same output)
+          bf16x4 a4[4], g4[4], u4[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              // same rounding as the unfused pair: gate|up are rounded to bf16 first (sd_swiglu_fwd reads them back)
+              const bf16 gb = (bf16)acc[i][j][e], ub = (bf16)acc[i][j + 4][e];
+              const float gf = (float)gb, uf = (float)ub;
+              g4[j][e] = gb; u4[j][e] = ub;
+              a4[j][e] = (bf16)(gf / (1.f + __expf(-gf)) * uf);
+            }
+          const int gc0 = tn * 128 + wn * 64;
+          store_rows(a4, ea.out2, ea.ld2, gm0, gc0, ea.I);
+          if (C) {
+            store_rows(g4, C, ldc, gm0, gc0, ea.I);
+            store_rows(u4, C + ea.I, ldc, gm0, gc0, ea.I);
+          }
+        } else {
+#pragma unroll
+          for (int jh = 0; jh < 2; ++jh) {
+            bf16x4 o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) o[j][e] = (bf16)acc[i][4 * jh + j][e];
+            store_rows(o, C, ldc, gm0, tn * BNN + wn * 128 + jh * 64, N);
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    cur_i = (cur_i == NST - 1) ? 0 : cur_i + 1;
+    nxt_i = (nxt_i == NST - 1) ? 0 : nxt_i + 1;
+  }
+  if (half == 0) __builtin_amdgcn_s_barrier();  // re-align the halves
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the tail prefetches before the workgroup retires
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Grouped form of the persistent kernel for the weight gradients of one decoder layer: up to 4 independent problems
 // C_p[M_p,N_p] = A_p^T . B_p with a common contraction length K (the tokens of the micro-batch), both operands stored
 // [K][rows] (dY and X as they lie in HBM).  Separately the four dW GEMMs of a Qwen3 layer have 64-192 tiles of
@@ -1114,12 +1314,33 @@ int launch(const void* A, const void* B, void* C, const void* R, float* slabs, i
       return 0;
     return cus & ~7;
   }();
+  static const bool p256_ok = !getenv("SD_GEMM_NO_P256");  // A/B measurements
+  // Measured (tests/bench_p256.py, MI355X): the 256 x 256 kernel ties the 256 x 128 one on the lm_head class (544 vs
+  // 557 us student, 924 vs 929 us teacher) and loses on gate|up (114 vs 93 us teacher, 37.6 vs 36.3 us student): both
+  // settle at ~0.9 us per staged K-step whatever the bytes of the step, i.e. the loop is paced by the latency of the
+  // operand stream at the LDS-limited prefetch depth, not by L2 -> LDS bandwidth per FLOP.  So only the vocabulary-wide
+  // GEMMs take it.  SD_GEMM_P256_MIN_TILES lowers the threshold for measurements / tests.
+  static const int p256_min_tiles = getenv("SD_GEMM_P256_MIN_TILES") ? atoi(getenv("SD_GEMM_P256_MIN_TILES")) : 1024;
   static const int gm_env = getenv("SD_GEMM_GROUP_M") ? atoi(getenv("SD_GEMM_GROUP_M")) : 0;  // A/B measurements
   int gm = gm_env > 0 ? gm_env : (BM == 256 ? 4 : 8);
   if (gm > tiles_m) gm = tiles_m;
   const bool fast = !g_no_fast_stage && (TA || TB || (K % BK) == 0) && span < 0x7fffffffL && span_b < 0x7fffffffL;
 #define SD_GEMM_GO(EPI)                                                                                              \
   do {                                                                                                               \
+    if constexpr (BM == 256 && NST == 9 && !TA && !TB && (EPI == 0 || EPI == 3)) {                                   \
+      /* many-column forward GEMMs: 256 x 256 tiles when they still fill >= 70 % of the CUs' rounds */               \
+      const int t_m = (M + 255) / 256, t_n = (EPI == 3) ? (ea.I + 127) / 128 : (N + 255) / 256, nt2 = t_m * t_n;       \
+      const int rounds = persist_grid > 0 ? (nt2 + persist_grid - 1) / persist_grid : 0;                              \
+      if (splits == 1 && !R && p256_ok && persist_grid > 0 && (K % P2_BK) == 0 && (EPI != 3 || (ea.I % 128) == 0) &&   \
+          (N % 8) == 0 && nt2 >= p256_min_tiles && 10 * nt2 >= 7 * rounds * persist_grid && span < 0x7fffffffL &&      \
+          span_b < 0x7fffffffL) {                                                                                     \
+        const int grid2 = nt2 > persist_grid ? persist_grid : nt2;                                                    \
+        SD_PROF_LABEL("gemm_p256_kernel<%d>", EPI);                                                                   \
+        hipLaunchKernelGGL((gemm_p256_kernel<EPI>), dim3(grid2), dim3(512), 0, st, (const bf16*)A, (const bf16*)B,     \
+                           (bf16*)C, M, N, K, lda, ldb, ldc, t_m, t_n, t_m < 8 ? t_m : 8, ea);                         \
+        break;                                                                                                         \
+      }                                                                                                                \
+    }                                                                                                                  \
     if constexpr (BM == 256 && NST == 9 && (EPI == 0 || EPI == 3)) {                                                 \
       if (splits == 1 && tiles_m * tiles_n > persist_grid && persist_grid > 0) {                                       \
         SD_PROF_LABEL("gemm_pstag_kernel<4, %s, %s, %d>", TA ? "true" : "false", TB ? "true" : "false", EPI);          \

@@ -15,6 +15,9 @@ import torch
 from conftest import GOLDEN, load_golden
 
 pytestmark = pytest.mark.gpu
+# the 256x256 persistent GEMM serves only vocabulary-wide GEMMs by default; the tests reach it at small sizes
+# (read once, at the first GEMM launch of the process)
+os.environ.setdefault("SD_GEMM_P256_MIN_TILES", "150")
 
 
 @pytest.fixture(scope="module")
@@ -175,8 +178,41 @@ def test_gemm_persistent_kernel(ops, ta, tb, K):
     assert torch.equal(outs[0], other)
 
 
+@pytest.mark.parametrize("K", [64, 192, 1088])
+def test_gemm_persistent_256x256_kernel(ops, K):
+    """Forward (NT) GEMMs with >= 150 tiles of 256x256 take gemm_p256_kernel (BK = 32 stages, 8 waves, 64x128 per wave):
+    K of 2, 6 and 34 steps per tile, ragged M and N edges, one K stream across tile boundaries; must equal the
+    128x128 kernel bit for bit (same accumulation order over k); run twice (race screen)."""
+    g = torch.Generator().manual_seed(100 + K)
+    M, N = 1000, 256 * 60 + 40
+    a = bf(torch.randn(M, K, generator=g))
+    b = bf(torch.randn(N, K, generator=g))
+    ad, bd = to_dev(a), to_dev(b)
+    lib = ops.load_lib()
+    ops.prof_begin()
+    outs = [ops.gemm(ad, bd), ops.gemm(ad, bd)]
+    ops.prof_end()
+    assert any(k.startswith("gemm_p256_kernel<0>") for k in ops.prof_symbols()), ops.prof_symbols()
+    lib.sd_gemm_force_variant(128, 3)
+    try:
+        other = ops.gemm(ad, bd)
+    finally:
+        lib.sd_gemm_force_variant(0, 0)
+    check_close(f"gemm_p256_K{K}", outs[0], _gemm_ref(a.float(), b.float(), False, False), 6e-3, 3e-3)
+    assert torch.equal(outs[0], outs[1])
+    assert torch.equal(outs[0], other)
+    # exact on small integers (any fragment / layout slip shows as a wrong integer)
+    ai = torch.randint(-3, 4, (M, K), generator=g).float()
+    bi = torch.randint(-3, 4, (N, K), generator=g).float()
+    ai[0, :] += 1.0
+    got = ops.gemm(to_dev(bf(ai)), to_dev(bf(bi))).float().cpu()
+    assert torch.equal(got, (ai.double() @ bi.double().t()).float().bfloat16().float())
+
+
 def test_gemm_persistent_swiglu(ops):
-    """gate|up GEMM + SwiGLU on the persistent kernel (I/64 * M/256 > number of CUs): bit-identical to GEMM + swiglu."""
+    """gate|up GEMM + SwiGLU on the persistent 256x256 kernel (tile = 128 gate rows | 128 up rows): bit-identical to
+    GEMM + swiglu; and on the 256x128 persistent kernel (SD_GEMM_NO_P256 is an A/B switch read at first use, so that
+    form is covered by test_gemm_fused_epilogues_equal_the_separate_kernels at forced variants)."""
     g = torch.Generator().manual_seed(5)
     M, K, I = 1100, 192, 64 * 90
     x = to_dev(bf(torch.randn(M, K, generator=g)))
@@ -188,7 +224,10 @@ def test_gemm_persistent_swiglu(ops):
     finally:
         lib.sd_gemm_force_variant(0, 0)
     act_ref = ops.swiglu_fwd(gu_ref)
+    ops.prof_begin()
     act, gu = ops.gemm_swiglu(x, wgu)
+    ops.prof_end()
+    assert any(k.startswith("gemm_p256_kernel<3>") for k in ops.prof_symbols()), ops.prof_symbols()  # 5 x 45 tiles of 256x256
     act2, none = ops.gemm_swiglu(x, wgu, save_gu=False)
     assert torch.equal(gu, gu_ref) and none is None
     assert torch.equal(act, act_ref) and torch.equal(act2, act_ref)
