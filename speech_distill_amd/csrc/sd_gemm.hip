@@ -75,18 +75,23 @@ template <bool TX, int ROWS, int NW>
 struct FastStage {
   static constexpr int NI = ROWS / (8 * NW);
   int voff[NI];
+  int first_piece;
 #if defined(__HIP_DEVICE_COMPILE__)  // the descriptor type only exists in the device pass; the host pass only needs the stub
   __amdgpu_buffer_rsrc_t rsrc;
 #endif
   long kstep;  // bytes per k element step of BK
   // hi_delta: rows 64.. of the tile come from row0 + r + hi_delta (EPI 3: the up-projection rows)
-  SD_DEV void init(const bf16* g, long ld, int row0, unsigned num_bytes, int w, int lane, int hi_delta = 0) {
+  // piece0 >= 0: this wave stages the NI consecutive 1 KiB pieces piece0 .. piece0+NI-1 of the tile (default: w*NI ..)
+  SD_DEV void init(const bf16* g, long ld, int row0, unsigned num_bytes, int w, int lane, int hi_delta = 0,
+                   int piece0 = -1) {
 #if defined(__HIP_DEVICE_COMPILE__)
     rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)g, 0, (int)num_bytes, 0x00020000);
 #endif
+    if (piece0 < 0) piece0 = w * NI;
+    first_piece = piece0;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-      const int p = (w * NI + i) * 64 + lane;
+      const int p = (piece0 + i) * 64 + lane;
       if constexpr (!TX) {
         const int r = p >> 3, s = p & 7, c = s ^ (r & 7);
         voff[i] = (int)((((long)(row0 + r + (r >= 64 ? hi_delta : 0))) * ld + c * 8) * 2);
@@ -104,7 +109,7 @@ struct FastStage {
     const int soff = (int)(k0 * kstep);
 #pragma unroll
     for (int i = 0; i < NI; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (SD_LDS void*)(lds_tile + (w * NI + i) * 1024), 16, voff[i], soff, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (SD_LDS void*)(lds_tile + (first_piece + i) * 1024), 16, voff[i], soff, 0, 0);
 #endif
   }
 };
@@ -562,7 +567,16 @@ __global__ __launch_bounds__(768) void gemm_pstag_kernel(const bf16* __restrict_
   constexpr int BM = 64 * MT, NW = 8, NPROD = 4, NST = 3, DEPTH = NST - 1;
   constexpr int WR = 16 * MT;                                                             // rows of C per compute wave
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;  // 48 / 32 KiB
-  constexpr int LOADS = (BM + BN) / (8 * NPROD);                                          // per producer wave per stage
+  // LDS-DMA issue is what paces the K loop: one buffer_load ... lds costs the issuing wave ~140 cycles, serially, so
+  // the 48 pieces of a stage took the 4 producers 12 x 140 = 1 650 cycles -- exactly the measured 0.81 us per K-step
+  // (and the 8 self-issuing waves of gemm_stag_kernel 6 x 140 + reads + 512 of MFMA, the same 0.81 us).  Spread over
+  // more waves the pieces overlap until the CU's address path (16 cycles a piece) or the MFMAs (2 x 512) bound the
+  // step: the producers keep B and the first half of A (8 pieces each, ~1 100 cycles), every compute wave adds 2
+  // pieces of the second half of A to its LOAD phase (2 x 140 + 16 reads, still under the partner's 512 of MFMA).
+  constexpr int A_PIECES = BM / 8, B_PIECES = BN / 8;           // 1 KiB pieces per stage: 32 + 16
+  constexpr int CW = (A_PIECES / 2) / NW;                       // A pieces per compute wave and stage: 2
+  constexpr int PA = (A_PIECES / 2) / NPROD, PB = B_PIECES / NPROD;  // per producer wave and stage: 4 + 4
+  constexpr int LOADS = PA + PB;
   constexpr int PATCH = 2048;                                                             // per compute wave
   __shared__ __attribute__((aligned(16))) char smem[NST * STAGE + NW * PATCH];            // ring + store patches <= 160 KiB
   const int lane = lane_id();
@@ -587,9 +601,10 @@ __global__ __launch_bounds__(768) void gemm_pstag_kernel(const bf16* __restrict_
   //        phases 2g-2 / 2g-1 and completed (lgkmcnt(0)) before those phases' closing barriers.
   if (w >= NW) {
     const int pw = w - NW;
-    FastStage<TA, BM, NPROD> fa;
+    FastStage<TA, BM, A_PIECES / PA> fa;  // NI = PA pieces: pieces pw*PA .. of the first half of the A tile
     FastStage<TB, BN, NPROD> fb;
-    fa.init(A, lda, 0, (unsigned)((TA ? ((long)(K - 1) * lda + M) : ((long)(M - 1) * lda + K)) * 2), pw, lane);
+    static_assert(FastStage<TA, BM, A_PIECES / PA>::NI == PA && FastStage<TB, BN, NPROD>::NI == PB, "piece split");
+    fa.init(A, lda, 0, (unsigned)((TA ? ((long)(K - 1) * lda + M) : ((long)(M - 1) * lda + K)) * 2), pw, lane, 0, pw * PA);
     fb.init(B, ldb, 0, (unsigned)((TB ? ((long)(K - 1) * ldb + N) : ((long)(N - 1) * ldb + K)) * 2), pw, lane,
             EPI == 3 ? ea.I - 64 : 0);
     int pf_tile = 0, pf_k = 0;
@@ -607,9 +622,9 @@ __global__ __launch_bounds__(768) void gemm_pstag_kernel(const bf16* __restrict_
       const int sa = (int)(pf_a + (unsigned)(pf_k * BK) * (unsigned)fa.kstep);
       const int sb = (int)(pf_b + (unsigned)(pf_k * BK) * (unsigned)fb.kstep);
 #pragma unroll
-      for (int i = 0; i < FastStage<TA, BM, NPROD>::NI; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(
-            fa.rsrc, (SD_LDS void*)(stage + (pw * FastStage<TA, BM, NPROD>::NI + i) * 1024), 16, fa.voff[i], sa, 0, 0);
+      for (int i = 0; i < PA; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(fa.rsrc, (SD_LDS void*)(stage + (pw * PA + i) * 1024), 16, fa.voff[i], sa, 0,
+                                                 0);
 #pragma unroll
       for (int i = 0; i < FastStage<TB, BN, NPROD>::NI; ++i)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(
@@ -646,10 +661,40 @@ __global__ __launch_bounds__(768) void gemm_pstag_kernel(const bf16* __restrict_
   for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // this wave's share of the operand stream: CW pieces of the second half of every A stage, issued in LOAD(g) for
+  // K-step g+DEPTH and retired by a counted vmcnt before the barrier that closes the phase (the same RAW / WAR
+  // argument as the producers'; a finished tile's stores sit in the same in-order counter, so the first wait after a
+  // tile boundary also waits for them)
+  FastStage<TA, BM, A_PIECES / CW> fc;
+  static_assert(FastStage<TA, BM, A_PIECES / CW>::NI == CW, "piece split");
+  fc.init(A, lda, 0, (unsigned)((TA ? ((long)(K - 1) * lda + M) : ((long)(M - 1) * lda + K)) * 2), w, lane, 0,
+          A_PIECES / 2 + w * CW);
+  int cf_tile = 0, cf_k = 0;
+  unsigned cf_a = 0;
+  auto cf_set = [&](int idx) {
+    int tm = 0, tn = 0;
+    if (idx < my_tiles) origin(idx, tm, tn);
+    const long m0 = (long)tm * BM;
+    cf_a = (unsigned)((TA ? m0 : m0 * lda) * 2);
+  };
+  auto cf_issue = [&](char* stage) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int sa = (int)(cf_a + (unsigned)(cf_k * BK) * (unsigned)fc.kstep);
+#pragma unroll
+    for (int i = 0; i < CW; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(fc.rsrc, (SD_LDS void*)(stage + (A_PIECES / 2 + w * CW + i) * 1024), 16,
+                                               fc.voff[i], sa, 0, 0);
+#endif
+    if (++cf_k == nk) { cf_k = 0; cf_set(++cf_tile); }
+  };
+  cf_set(0);
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) cf_issue(smem + d * STAGE);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                 // the first DEPTH K-steps have landed
   if (half == 1) __builtin_amdgcn_s_barrier();  // second half runs one phase behind
 
-  int cur_i = 0, ck = 0, ctile = 0;
+  int cur_i = 0, cnx_i = DEPTH, ck = 0, ctile = 0;
   // The finished 16 x 64 blocks of this wave go through an LDS patch of the wave's own (XOR-swizzled 16-byte chunks) so
   // that a store instruction writes whole 128-byte lines instead of 16 x 4 pieces of 32 B (-1.1 us per tile).
   // Spreading the stores over the K-steps of the next tile (all CUs reach their tile boundary together) was
@@ -677,7 +722,9 @@ __global__ __launch_bounds__(768) void gemm_pstag_kernel(const bf16* __restrict_
     }
   };
   for (int g = 0; g < total; ++g) {
-    // ---- LOAD(g): fragments of K-step g
+    // ---- LOAD(g): my pieces of K-step g+DEPTH, fragments of K-step g
+    cf_issue(smem + cnx_i * STAGE);
+    cnx_i = (cnx_i == NST - 1) ? 0 : cnx_i + 1;
     const char* cur = smem + cur_i * STAGE;
     bf16x8 af[2][MT], bfr[2][4];
 #pragma unroll
@@ -700,6 +747,7 @@ __global__ __launch_bounds__(768) void gemm_pstag_kernel(const bf16* __restrict_
         for (int j = 0; j < 4; ++j) bfr[kk][j] = load_frag<TB, BN>(cur + A_BYTES, wn * 64 + j * 16, kk, lane);
       }
     }
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DEPTH - 1) * CW) : "memory");  // my pieces of K-step g+1 have landed
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
@@ -755,6 +803,7 @@ __global__ __launch_bounds__(768) void gemm_pstag_kernel(const bf16* __restrict_
     cur_i = (cur_i == NST - 1) ? 0 : cur_i + 1;
   }
   if (half == 0) __builtin_amdgcn_s_barrier();  // re-align the halves
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain my tail prefetches before the workgroup retires
 }
 
 // ---------------------------------------------------------------------------------------------------
