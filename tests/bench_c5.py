@@ -53,15 +53,21 @@ labels[:, : T // 4] = -100
 loss_fn = sda.DistillationLoss(2.0, 0.5, inplace_grad=True)
 
 
-def c4():
+side = torch.cuda.Stream(device=dev)
+
+
+def c4():  # the sequence of DistillationTrainer.compute_loss on a training step: loss rows only, teacher on a side stream
     student.zero_grad()
-    logits = student(input_ids=ids).logits
-    with torch.no_grad():
-        tv, ti = ops.logsoftmax_topk(teacher(input_ids=ids).logits, 128)
-    loss_fn(logits, labels, teacher_top_k_v=tv, teacher_top_k_i=ti)[0].backward()
+    rows, row_labels = ops.loss_rows(labels)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.no_grad(), torch.cuda.stream(side):
+        tv, ti = ops.logsoftmax_topk(teacher(input_ids=ids, logit_rows=rows).logits, 128)
+    logits = student(input_ids=ids, logit_rows=rows).logits
+    torch.cuda.current_stream().wait_stream(side)
+    loss_fn.forward_rows(logits, row_labels, teacher_top_k_v=tv, teacher_top_k_i=ti)[0].backward()
 
 
 dt = timeit(c4, n=3, w=1)
 f = 3 * flops_per_token(STUDENT_06B, T) + flops_per_token(TEACHER_17B, T)
-print(json.dumps({"config": "C4-shaped step B=4 T=2048 (1 GPU)", "tokens_per_s": B * T / dt, "ms": dt * 1e3,
+print(json.dumps({"config": "C4-shaped step B=4 T=2048 (1 GPU), head on the loss rows, teacher beside the student", "tokens_per_s": B * T / dt, "ms": dt * 1e3,
                   "mfma_frac": B * T / dt * f / 2.5e15}), flush=True)
