@@ -20,7 +20,8 @@ class SdHipError(RuntimeError):
 
 
 def lib_path() -> str:
-    return os.path.join(_HERE, "libsd_hip.so")
+    # SD_HIP_LIB: a diagnostic build of the same library (make -C speech_distill_amd/csrc stamps), measurements only
+    return os.environ.get("SD_HIP_LIB") or os.path.join(_HERE, "libsd_hip.so")
 
 
 class Dims(C.Structure):

@@ -586,6 +586,29 @@ __global__ __launch_bounds__(768) void gemm_pstag_kernel(const bf16* __restrict_
   // my tiles: xcd_remap(blockIdx.x + k * gridDim.x) (gridDim.x is a multiple of 8, or ntiles itself)
   const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
   const int total = my_tiles * nk;  // K-steps of this workgroup
+#ifdef SD_STAMPS
+  // DIAGNOSTIC BUILD ONLY (make stamps): s_memtime at the phase boundaries of K-steps 4..19 of workgroup 0, kept in the
+  // wave's idle store patch (LDS) and dumped to ea.cos_t right after the window: [wave 0..11][step 0..15][point 0..5]
+  unsigned long long* const stamp_out = (unsigned long long*)ea.cos_t;
+  const bool stamping = stamp_out && blockIdx.x == 0;
+#define SD_STAMP(G, PT)                                                                                   \
+  do {                                                                                                    \
+    if (stamping && (G) >= 4 && (G) < 20 && lane == 0)                                                    \
+      ((unsigned long long*)(smem + NST * STAGE + (w & 7) * PATCH + (w >= NW ? 1024 : 0)))[((G) - 4) * 6 + (PT)] = \
+          __builtin_amdgcn_s_memtime();                                                                   \
+  } while (0)
+#define SD_STAMP_DUMP(G)                                                                                  \
+  do {                                                                                                    \
+    if (stamping && (G) == 20 && lane < 48) {                                                             \
+      const unsigned long long* src = (const unsigned long long*)(smem + NST * STAGE + (w & 7) * PATCH + (w >= NW ? 1024 : 0)); \
+      stamp_out[w * 96 + lane] = src[lane];                                                               \
+      stamp_out[w * 96 + 48 + lane] = src[48 + lane];                                                     \
+    }                                                                                                     \
+  } while (0)
+#else
+#define SD_STAMP(G, PT) do { } while (0)
+#define SD_STAMP_DUMP(G) do { } while (0)
+#endif
   auto origin = [&](int idx, int& tm, int& tn) {
     const int t = xcd_remap((int)blockIdx.x + idx * (int)gridDim.x, ntiles);
     tile_coords(t, tiles_m, tiles_n, group_m, tm, tn);
@@ -642,11 +665,17 @@ __global__ __launch_bounds__(768) void gemm_pstag_kernel(const bf16* __restrict_
     for (int g = 0; g < total; ++g) {
       // phase 2g: K-step g+DEPTH of the stream (steps past the end re-read the first origin and are never used);
       // then everything up to K-step g+1 has landed
+      SD_STAMP_DUMP(g);
+      SD_STAMP(g, 0);
       pf_issue(smem + nxt * STAGE);
       nxt = (nxt == NST - 1) ? 0 : nxt + 1;
+      SD_STAMP(g, 1);
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DEPTH - 1) * LOADS) : "memory");
+      SD_STAMP(g, 2);
       __builtin_amdgcn_s_barrier();
+      SD_STAMP(g, 3);
       __builtin_amdgcn_s_barrier();  // phase 2g+1: nothing to do
+      SD_STAMP(g, 4);
     }
     __builtin_amdgcn_s_barrier();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the tail prefetches before the workgroup retires
@@ -723,6 +752,8 @@ __global__ __launch_bounds__(768) void gemm_pstag_kernel(const bf16* __restrict_
   };
   for (int g = 0; g < total; ++g) {
     // ---- LOAD(g): my pieces of K-step g+DEPTH, fragments of K-step g
+    SD_STAMP_DUMP(g);
+    SD_STAMP(g, 0);
     cf_issue(smem + cnx_i * STAGE);
     cnx_i = (cnx_i == NST - 1) ? 0 : cnx_i + 1;
     const char* cur = smem + cur_i * STAGE;
@@ -747,11 +778,14 @@ __global__ __launch_bounds__(768) void gemm_pstag_kernel(const bf16* __restrict_
         for (int j = 0; j < 4; ++j) bfr[kk][j] = load_frag<TB, BN>(cur + A_BYTES, wn * 64 + j * 16, kk, lane);
       }
     }
+    SD_STAMP(g, 1);
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DEPTH - 1) * CW) : "memory");  // my pieces of K-step g+1 have landed
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    SD_STAMP(g, 2);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
+    SD_STAMP(g, 3);
     // ---- COMPUTE(g)
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -797,14 +831,19 @@ __global__ __launch_bounds__(768) void gemm_pstag_kernel(const bf16* __restrict_
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
     }
+    SD_STAMP(g, 4);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
+    SD_STAMP(g, 5);
     cur_i = (cur_i == NST - 1) ? 0 : cur_i + 1;
   }
   if (half == 0) __builtin_amdgcn_s_barrier();  // re-align the halves
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain my tail prefetches before the workgroup retires
 }
+
+#undef SD_STAMP
+#undef SD_STAMP_DUMP
 
 // ---------------------------------------------------------------------------------------------------
 // Persistent 256 x 256 kernel for the forward (NT) GEMMs with many output columns: lm_head (N = vocabulary) and gate|up.
@@ -1339,6 +1378,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   }
 }
 
+#ifdef SD_STAMPS
+void* g_stamp_buffer = nullptr;  // diagnostic build: device buffer for the phase stamps of gemm_pstag_kernel
+#endif
 bool g_no_fast_stage = false;  // tests / A-B measurements: force the checked staging path
 thread_local bool g_skip_reduce = false;  // set by sd_gemm_bf16_splitk_partial around its dispatch
 
@@ -1374,6 +1416,13 @@ int launch(const void* A, const void* B, void* C, const void* R, float* slabs, i
   int gm = gm_env > 0 ? gm_env : (BM == 256 ? 4 : 8);
   if (gm > tiles_m) gm = tiles_m;
   const bool fast = !g_no_fast_stage && (TA || TB || (K % BK) == 0) && span < 0x7fffffffL && span_b < 0x7fffffffL;
+#ifdef SD_STAMPS
+#define SD_STAMP_ARGS() EpiArgs ea_st = ea; ea_st.cos_t = (const bf16*)g_stamp_buffer
+#define SD_STAMP_EA ea_st
+#else
+#define SD_STAMP_ARGS() do { } while (0)
+#define SD_STAMP_EA ea
+#endif
 #define SD_GEMM_GO(EPI)                                                                                              \
   do {                                                                                                               \
     if constexpr (BM == 256 && NST == 9 && !TA && !TB && (EPI == 0 || EPI == 3)) {                                   \
@@ -1393,9 +1442,10 @@ int launch(const void* A, const void* B, void* C, const void* R, float* slabs, i
     if constexpr (BM == 256 && NST == 9 && (EPI == 0 || EPI == 3)) {                                                 \
       if (splits == 1 && tiles_m * tiles_n > persist_grid && persist_grid > 0) {                                       \
         SD_PROF_LABEL("gemm_pstag_kernel<4, %s, %s, %d>", TA ? "true" : "false", TB ? "true" : "false", EPI);          \
+        SD_STAMP_ARGS();                                                                                               \
         hipLaunchKernelGGL((gemm_pstag_kernel<4, TA, TB, EPI>), dim3(persist_grid), dim3(768), 0, st, (const bf16*)A,  \
                            (const bf16*)B, (bf16*)C, (const bf16*)R, M, N, K, lda, ldb, ldc, ldr, tiles_m, tiles_n,    \
-                           gm, ea);                                                                                    \
+                           gm, SD_STAMP_EA);                                                                           \
         break;                                                                                                         \
       }                                                                                                                \
     }                                                                                                                  \
@@ -1518,6 +1568,10 @@ extern "C" int sd_gemm_bf16(const void* A, const void* B, void* C, const void* R
   if (int e = check_args(A, B, C, R, M, N, K, lda, ldb, ldc, ldr, trans_a, trans_b)) return e;
   return dispatch(A, B, C, R, nullptr, 1, M, N, K, lda, ldb, ldc, ldr, trans_a, trans_b, (hipStream_t)stream);
 }
+
+#ifdef SD_STAMPS
+extern "C" void sd_debug_stamp_buffer(void* p) { g_stamp_buffer = p; }
+#endif
 
 extern "C" void sd_gemm_force_variant(int bm, int nst) {
   g_no_fast_stage = (nst & 0x100) != 0;  // nst | 0x100: checked (pointer) staging instead of buffer descriptors
