@@ -145,6 +145,18 @@ SD_DEV void load_frags_tr(const char* lds_tile, int row_base, int kk, int lane, 
   for (int f = 0; f < NF; ++f) out[f] = cat8_u64(raw[2 * f], raw[2 * f + 1]);
 }
 
+// ---- 32-deep stage images (rows of 64 B = 4 chunks): gemm_p256_kernel
+constexpr int P2_BK = 32;
+// chunk XOR of image row r: ds_read_b128 serves lanes in the groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ... (rows
+// {0-3,12-15} at k-chunk c with rows {4-11} at c^1): with g(r>>2) = 0,3,2,1 the 16 lanes of every group fall on 16
+// different 16-byte slots of the 256-byte bank row (the plain (r>>2)&3 gives 2-way conflicts: 0.9 instead of 0.5 us
+// per K-step).
+SD_DEV int swz32(int r) { return (0 - (r >> 2)) & 3; }
+SD_DEV bf16x8 load_frag32(const char* tile, int row16_base, int lane) {  // 16 rows x 32 k: lane l = row l&15, k 8(l>>4)..
+  const int r = row16_base + (lane & 15), c = lane >> 4;
+  return *(const bf16x8*)(tile + r * 64 + ((c ^ swz32(r)) << 4));
+}
+
 // Extra operands of the fused epilogues.
 //   EPI 3 (gate|up GEMM + SwiGLU, HF:81-83): the B tile of column-tile tn is gate rows [64tn,64tn+64) followed by up
 //          rows [I+64tn, ...), so a 128-column C tile holds gate and up of the SAME 64 outputs; act = silu(gate)*up
@@ -558,7 +570,11 @@ __global__ __launch_bounds__(512, 2) void gemm_stag_kernel(const bf16* __restric
 //   EPI 0: C = A.B          EPI 3: SwiGLU (B tile = 64 gate rows | 64 up rows; each wave reads 32 + 32 of them, so gate
 //   and up of the same outputs sit in the same lane: act = silu(gate) * up in registers, out2 [M, I]).
 // (A 128 x 128 form of this kernel with a 4-stage ring was measured on the N = hidden shapes: no faster than the
-// 4-wave gemm_bf16_kernel<128, 3>, so it is not kept.)
+// 4-wave gemm_bf16_kernel<128, 3>, so it is not kept.  Round 2 built, verified bit-identical and measured two
+// single-barrier forms on the gate|up / lm_head shapes -- 8 waves with whole K-steps of fragments double-buffered in
+// registers and self-issued DMA, halves in opposite orders (teacher gate|up 107.6 us, lm_head 983 us), and 8 + 4 waves
+// with half-step fragment double buffering over a ring of six 32-deep half-stages (123.8 / 1 115 us) -- against this
+// kernel's 97.0 / 892 us: not kept either)
 template <int MT, bool TA, bool TB, int EPI>
 __global__ __launch_bounds__(768) void gemm_pstag_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B, bf16* C,
                                                          const bf16* R, int M, int N, int K, long lda, long ldb, long ldc,
@@ -863,16 +879,6 @@ __global__ __launch_bounds__(768) void gemm_pstag_kernel(const bf16* __restrict_
 // A workgroup walks its tiles as ONE K stream (the tile origin is a scalar offset of the buffer load); a finished
 // 16 x 64 block leaves through the wave's 2 KiB LDS patch as whole 128-byte lines.
 //   EPI 0: C = A.B^T     EPI 3: SwiGLU, B tile = 128 gate rows | 128 up rows: gate and up of one output sit in one lane.
-constexpr int P2_BK = 32;
-// chunk XOR of image row r: ds_read_b128 serves lanes in the groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ... (rows
-// {0-3,12-15} at k-chunk c with rows {4-11} at c^1): with g(r>>2) = 0,3,2,1 the 16 lanes of every group fall on 16
-// different 16-byte slots of the 256-byte bank row (the plain (r>>2)&3 gives 2-way conflicts: 0.9 instead of 0.5 us
-// per K-step).
-SD_DEV int swz32(int r) { return (0 - (r >> 2)) & 3; }
-SD_DEV bf16x8 load_frag32(const char* tile, int row16_base, int lane) {  // 16 rows x 32 k: lane l = row l&15, k 8(l>>4)..
-  const int r = row16_base + (lane & 15), c = lane >> 4;
-  return *(const bf16x8*)(tile + r * 64 + ((c ^ swz32(r)) << 4));
-}
 template <int EPI>
 __global__ __launch_bounds__(512) void gemm_p256_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B, bf16* C, int M,
                                                         int N, int K, long lda, long ldb, long ldc, int tiles_m,
