@@ -11,10 +11,11 @@
  *     16-byte aligned, leading dimensions are in ELEMENTS and multiples of 8;
  *   - `stream` is a hipStream_t (torch's current stream); launchers never allocate device memory and never
  *     synchronise; scratch comes from the caller (see *_workspace_bytes).  Process state is limited to:
- *     (1) a pool of timing-disabled hipEvent_t sets, leased per sd_qwen3_backward* call and per device (two
+ *     (1) a pool of timing-disabled hipEvent_t sets, leased per sd_qwen3_backward* / sd_attn_bwd2 call and per device (two
  *     concurrent backward calls never share an event); (2) the sd_prof_* accumulators (only between
  *     sd_prof_begin/end); (3) measurement switches meant for tests and benchmarks, not for production use:
- *     sd_gemm_force_variant() and the environment variables SD_OVERLAP_MASK / SD_FUSE_STUDENT_SWIGLU, read once;
+ *     sd_gemm_force_variant() and the environment variables SD_OVERLAP_MASK, SD_FUSE_STUDENT_SWIGLU, SD_GEMM_NO_P256,
+ *     SD_GEMM_P256_MIN_TILES, SD_GEMM_NO_PERSIST, SD_GEMM_GROUP_M, SD_TOPK_NT (A/B switches, each read once);
  *   - return value: SD_OK (0), a negative SD_ERR_* code, or a positive hipError_t from the launch.
  */
 #pragma once

@@ -19,6 +19,7 @@
 #include "sd_common.cuh"
 #include "../../include/sd_hip.h"
 #include "sd_prof.h"
+#include "sd_events.h"
 
 namespace {
 
@@ -594,11 +595,6 @@ extern "C" int sd_attn_fwd(const void* q, const void* k, const void* v, void* o,
   return 0;
 }
 
-namespace {
-hipEvent_t g_attn_ev[2];
-bool g_attn_ev_ready = false;
-}  // namespace
-
 extern "C" int sd_attn_bwd2(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse,
                             float* delta, void* dq, void* dk, void* dv, const int32_t* kv_len, int64_t ldq, int64_t ldk,
                             int64_t ldv, int64_t ldo, int64_t lddq, int64_t lddk, int64_t lddv, int B, int T, int Hq,
@@ -607,11 +603,9 @@ extern "C" int sd_attn_bwd2(const void* q, const void* k, const void* v, const v
   if (int e = check_common(B, T, Hq, Hkv, ldq, ldk, ldv, ldo)) return e;
   if ((lddq | lddk | lddv) & 7) return SD_ERR_ALIGN;
   hipStream_t st = (hipStream_t)stream, s2 = (hipStream_t)side_stream;
-  if (s2 && !g_attn_ev_ready) {
-    for (auto& e : g_attn_ev)
-      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return SD_ERR_WORKSPACE;
-    g_attn_ev_ready = true;
-  }
+  SdEventLease lease;  // this call's events (per call, per device)
+  if (s2 && !(lease.set = sd_lease_events())) return SD_ERR_WORKSPACE;
+  hipEvent_t* g_attn_ev = lease.set ? lease.set->ev : nullptr;
   const long total = (long)B * T * Hq;
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, st, (const bf16*)d_o,
                      (const bf16*)o, delta, ldo, T, Hq, total);

@@ -6,9 +6,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
-#include <mutex>
-#include <vector>
 #include "../../include/sd_hip.h"
+#include "sd_events.h"
 
 namespace {
 
@@ -85,34 +84,28 @@ struct BwdScratch {
 
 #define RUN(call) do { int e__ = (call); if (e__) return e__; } while (0)
 
-// Events ordering the optional side stream against the main one (timing disabled).  A backward call leases one set
-// for its duration from a small per-device pool: two models running backward at the same time (different host
-// threads) or on different devices never share an event, and nothing is created on the steady-state path.  An event
-// may be re-recorded by a later call while a wait enqueued by an earlier one is still pending: hipStreamWaitEvent
-// captures the record that was current when it was issued.
-constexpr int kNumEvents = 12;
-struct EventSet {
-  hipEvent_t ev[kNumEvents];
-  int device;
-};
-std::mutex g_ev_mu;
-std::vector<EventSet*> g_ev_free;
+}  // namespace
 
-EventSet* lease_events() {
+namespace {
+std::mutex g_ev_mu;
+std::vector<SdEventSet*> g_ev_free;
+}  // namespace
+
+SdEventSet* sd_lease_events() {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return nullptr;
   {
     std::lock_guard<std::mutex> lk(g_ev_mu);
     for (size_t i = 0; i < g_ev_free.size(); ++i)
       if (g_ev_free[i]->device == dev) {
-        EventSet* s = g_ev_free[i];
+        SdEventSet* s = g_ev_free[i];
         g_ev_free.erase(g_ev_free.begin() + i);
         return s;
       }
   }
-  EventSet* s = new EventSet;
+  SdEventSet* s = new SdEventSet;
   s->device = dev;
-  for (int i = 0; i < kNumEvents; ++i)
+  for (int i = 0; i < kSdEventsPerSet; ++i)
     if (hipEventCreateWithFlags(&s->ev[i], hipEventDisableTiming) != hipSuccess) {
       for (int j = 0; j < i; ++j) (void)hipEventDestroy(s->ev[j]);
       delete s;
@@ -120,18 +113,10 @@ EventSet* lease_events() {
     }
   return s;
 }
-
-struct EventLease {
-  EventSet* set = nullptr;
-  ~EventLease() {
-    if (set) {
-      std::lock_guard<std::mutex> lk(g_ev_mu);
-      g_ev_free.push_back(set);
-    }
-  }
-};
-
-}  // namespace
+void sd_return_events(SdEventSet* s) {
+  std::lock_guard<std::mutex> lk(g_ev_mu);
+  g_ev_free.push_back(s);
+}
 
 extern "C" int sd_abi_version(void) { return 1; }
 
@@ -256,8 +241,8 @@ extern "C" int sd_qwen3_backward_rows(const sd_qwen3_dims* d, const sd_qwen3_par
   // A/B switch for measurements: SD_OVERLAP_MASK bit0 lm_head dW, bit1 gain reduces, bit2 attention dQ, bit3 grouped per-layer dW, bit4 batched per-layer gain reduce (default all on)
   static const int ovl = getenv("SD_OVERLAP_MASK") ? atoi(getenv("SD_OVERLAP_MASK")) : 31;
   hipStream_t s1 = (hipStream_t)stream, s2 = (hipStream_t)side_stream;
-  EventLease lease;
-  if (s2 && !(lease.set = lease_events())) return SD_ERR_WORKSPACE;
+  SdEventLease lease;
+  if (s2 && !(lease.set = sd_lease_events())) return SD_ERR_WORKSPACE;
   hipEvent_t* g_ev = lease.set ? lease.set->ev : nullptr;  // this call's events
   void* wstream = s2 ? side_stream : stream;  // where weight-gradient GEMMs go
   // main -> side: "this buffer is final"; side -> main: "this layer's dW GEMMs have read their inputs"
