@@ -261,7 +261,7 @@ def main():
         tmax = torch.tensor([dt], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax)
-    losses = [float(x) for x in out]
+    losses = [float(x.detach()) for x in out]
     grad_sync_ok = None
     if multi:  # after the all-reduce every rank must hold the same averaged gradient
         cs = student.flat_grad.float().abs().sum().double().reshape(1)

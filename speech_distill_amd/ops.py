@@ -351,6 +351,21 @@ def loss_rows(labels, speech_mask=None, right_padded=()):
     return rows, nxt.reshape(-1)[rows]
 
 
+def colsum_reduce_batch(problems):
+    """[(partials [nb, stride] fp32, out [H] bf16, H, accumulate), ...] (at most 8): out[c] (+)= sum_r partials[r, c] for
+    every problem in ONE launch (sd_colsum_reduce_batch: a layer's four gain gradients)."""
+    import ctypes as C
+    from ._lib import ColsumProblem
+    n = len(problems)
+    arr = (ColsumProblem * n)()
+    for i, (part, out, H, acc) in enumerate(problems):
+        _need(out, torch.bfloat16, "out")
+        if not part.is_cuda or part.dtype != torch.float32 or part.dim() != 2 or part.stride(1) != 1:
+            raise ValueError("partials: fp32 GPU matrix [nb, >= H] with unit column stride")
+        arr[i] = ColsumProblem(part.data_ptr(), out.data_ptr(), part.shape[0], H, part.stride(0), int(acc))
+    check(load_lib().sd_colsum_reduce_batch(C.cast(arr, C.c_void_p), n, _stream()), "sd_colsum_reduce_batch")
+
+
 def rows_scatter(src, rows, M):
     src = _need(src, torch.bfloat16, "src")
     dst = torch.empty(M, src.shape[1], dtype=torch.bfloat16, device=src.device)

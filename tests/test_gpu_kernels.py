@@ -358,6 +358,41 @@ def test_qknorm_rope_fwd_bwd(ops, O, B, T, Hq, Hkv):
     check_close(f"qknorm_rope_bwd_dkg_T{T}", dkg, kgr.grad, 1.5e-2, 5e-3)
 
 
+def test_colsum_reduce_batch(ops):
+    """Four column sums of different shapes in one launch (a layer's gain gradients), with and without accumulation,
+    a strided partial array (the q/k gain layout [nb][256]) and the deferred-reduce form of the RMSNorm backward."""
+    g = torch.Generator().manual_seed(3)
+    p1 = to_dev(torch.randn(512, 1024, generator=g))
+    p2 = to_dev(torch.randn(37, 2048, generator=g))
+    pq = to_dev(torch.randn(300, 256, generator=g))
+    o1 = to_dev(bf(torch.randn(1024, generator=g)))
+    o2 = to_dev(bf(torch.zeros(2048)))
+    oq, ok = to_dev(bf(torch.zeros(128))), to_dev(bf(torch.randn(128, generator=g)))
+    want1 = (o1.float() + p1.sum(0)).bfloat16()
+    wantk = (ok.float() + pq[:, 128:].sum(0)).bfloat16()
+    ops.colsum_reduce_batch([(p1, o1, 1024, True), (p2, o2, 2048, False), (pq, oq, 128, False), (pq[:, 128:], ok, 128, True)])
+    check_close("colsum_batch_1", o1, want1.double(), 8e-3)
+    check_close("colsum_batch_2", o2, p2.double().sum(0), 8e-3)
+    check_close("colsum_batch_q", oq, pq[:, :128].double().sum(0), 8e-3)
+    check_close("colsum_batch_k", ok, wantk.double(), 8e-3)
+    # deferred reduce == immediate reduce, bit for bit (same partials, same summation order)
+    lib = ops.load_lib()
+    M, H = 300, 1024
+    x, dy = to_dev(bf(torch.randn(M, H, generator=g))), to_dev(bf(torch.randn(M, H, generator=g)))
+    w = to_dev(bf(1 + 0.1 * torch.randn(H, generator=g)))
+    y, rstd = ops.rmsnorm_fwd(x, w)
+    dx_ref, dw_ref = ops.rmsnorm_bwd(dy, x, w, rstd)
+    ws = torch.empty(lib.sd_rmsnorm_bwd_workspace_bytes(M, H), dtype=torch.uint8, device=x.device)
+    dx = torch.empty_like(x)
+    rc = lib.sd_rmsnorm_bwd2(dy.data_ptr(), x.data_ptr(), w.data_ptr(), rstd.data_ptr(), 0, dx.data_ptr(), 0, 0, ws.data_ptr(),
+                             M, H, 0, 0, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    nb = lib.sd_rmsnorm_bwd_partial_rows(M, H)
+    dw = torch.zeros_like(w)
+    ops.colsum_reduce_batch([(ws.view(torch.float32)[:nb * H].view(nb, H), dw, H, False)])
+    assert torch.equal(dx, dx_ref) and torch.equal(dw, dw_ref)
+
+
 def test_swiglu_fwd_bwd(ops):
     g = torch.Generator().manual_seed(3)
     gu, dact = bf(torch.randn(70, 512, generator=g) * 2), bf(torch.randn(70, 256, generator=g))
