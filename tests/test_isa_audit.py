@@ -53,7 +53,8 @@ def test_asm_transposed_reads_are_waited_before_use(src):
             regs.update(int(m.group(1)) for m in re.finditer(r"\bv(\d+)\b", t))
             if regs & set(pending):
                 hazards.append((ln, t))
-    assert n_tr > 100, "expected the asm transposed reads in the kernels"
+    # sanity: the asm reads are really there (sd_attn.hip: 3 kernels x 32 after the round-2 backward rewrite = 96)
+    assert n_tr > (100 if src == "sd_gemm.hip" else 60), "expected the asm transposed reads in the kernels"
     # accumulators stay in VGPRs: no AGPR <-> VGPR copies around the VALU work (only the dK/dV kernel, whose two
     # accumulator sets exceed 256 registers, keeps a few)
     assert n_acc <= (0 if src == "sd_gemm.hip" else n_mfma * 2), (n_acc, n_mfma)
