@@ -131,12 +131,16 @@ SD_DEV void store_tile_rows(char* img, const f32x16 (&acc)[4], float mul, bf16* 
 }
 
 // ------------------------------------------------------------------------------------------ forward
-// grid (ceil(T/128), Hq, B), 512 threads.  Waves w and w+4 own the SAME 32 query rows q0 + 32(w&3) .. +31 and split
-// the K/V tiles between them (half = w>>2 takes tiles t = 2i + half): at B*T = 2048 tokens there are only 1 024
-// row-blocks of 32 queries, one wave per SIMD, and a single wave runs its DMA issue, LDS reads, MFMAs and softmax
-// VALU strictly one after the other (~5 000 cycles per K/V tile for 1 024 cycles of MFMA); with two independent
-// waves per SIMD they overlap.  Each half streams its own tiles through its own double buffer (2 x (K,V) = 64 KiB);
-// the two partial (m, l, O) states are merged through LDS at the end (fixed order: deterministic).
+// grid (ceil(ceil(T/64)/2), Hq, B), 512 threads.  Under the causal mask a 64-row query tile t sees t+1 K/V tiles, so
+// equal row ranges are unequal work (at T = 512: 2, 4, 6, 8 tiles for the four 128-row tiles, and the chip waits for the
+// heaviest).  A workgroup therefore takes a PAIR of 64-row query tiles, the j-th lightest and the j-th heaviest (every
+// pair sees ceil(T/64)+1 tiles in total): waves 0-3 own the heavy tile, waves 4-7 the light one, and since waves w and
+// w+4 share a SIMD every SIMD carries one wave of each.  Both tiles belong to the same (batch, head), so they read the
+// same K/V stream: ONE ring streams the heavy tile's K/V tiles, the light tile's waves use the first of them and then
+// only keep staging.  Inside a group of four: rb = w&1 is the 32-row block, half = (w>>1)&1 splits the K/V tiles
+// (tiles t = 2i + half, each half through its own double buffer, 2 x (K,V) x 2 stages = 64 KiB) -- with one wave per
+// SIMD a wave ran its DMA issue, LDS reads, MFMAs and softmax VALU strictly one after the other; two waves overlap
+// them.  The two partial (m, l, O) states of a row block are merged through LDS at the end (fixed order).
 __global__ __launch_bounds__(512) void attn_fwd_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ Kp,
                                                        const bf16* __restrict__ Vp, bf16* __restrict__ O,
                                                        float* __restrict__ LSE, const int* __restrict__ kv_len, long ldq,
@@ -144,11 +148,14 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const bf16* __restrict__ 
                                                        float scale) {
   __shared__ __attribute__((aligned(16))) char smem[8 * TILE];  // 2 halves x 2 stages x (K,V)
   const int lane = lane_id(), w8 = wave_id_uniform();
-  const int half = w8 >> 2, w = w8 & 3;
-  const int qt = gridDim.x - 1 - blockIdx.x;  // heaviest (latest) query tiles first
+  const int grp = w8 >> 2, rb = w8 & 1, half = (w8 >> 1) & 1;
+  const int w = grp * 2 + rb;  // 0..3 inside my half: staging share and merge slot
+  const int n64 = (T + 63) / 64;
+  const int tA = n64 - 1 - (int)blockIdx.x, tB = (int)blockIdx.x;  // heavy / light 64-row query tile of this workgroup
+  const bool active = grp == 0 || tB != tA;                      // odd tile count: the middle tile has no partner
   const int hq = blockIdx.y, b = blockIdx.z;
   const int hkv = hq / (Hq / Hkv);
-  const int q0 = qt * 128, q0w = q0 + 32 * w;
+  const int q0w = (grp == 0 ? tA : tB) * 64 + 32 * rb;
   const int r = lane & 31, h = lane >> 5;
   const int klen = kv_len ? max(1, min(kv_len[b], T)) : T;
   const long tok0 = (long)b * T;
@@ -171,7 +178,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const bf16* __restrict__ 
   float m = NEG, l = 0.f;
   const float c = scale * LOG2E;
 
-  const int kv_hi = min(q0 + 128, T);
+  const int kv_hi = min(tA * 64 + 64, T);  // the heavy tile's diagonal bounds the stream
   const int nkv = (kv_hi + 63) / 64;
   const int nit = (nkv + 1) >> 1;  // trips of both halves; half 1 idles through the last one when nkv is odd
   TileDma kd, vd;
@@ -196,7 +203,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const bf16* __restrict__ 
     const char* vs = ks + TILE;
     cur_i ^= 1;
     const int kv0 = (2 * i + half) * 64;
-    if (kv0 < kv_hi && kv0 <= q0w + 31) {  // wave-uniform: some key of this tile is visible to some row of this wave
+    if (active && kv0 < kv_hi && kv0 <= q0w + 31) {  // wave-uniform: some key of this tile is visible to some row of this wave
       const bool need_mask = (kv0 + 63 > q0w) || (kv0 + 63 >= klen);  // wave-uniform: tile touches the diagonal / padding
       f32x16 s[2];
 #pragma unroll
@@ -282,6 +289,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const bf16* __restrict__ 
   const float inv = 1.f / l;
   // every lane of a row has the same `inv` only after the two column halves are combined: lanes r and r+32 hold the
   // same row, and `l` was just summed over them, so scaling per lane before the transposing store is exact
+  if (!active) return;
   store_tile_rows((char*)xo, o, inv, O + (tok0 + q0w) * ldo + hq * D, ldo, T - q0w, lane);
   if (q < T && h == 0) LSE[((long)b * Hq + hq) * T + q] = m * scale + __logf(l);
 }
@@ -310,9 +318,11 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16* __restrict_
 }
 
 // ----------------------------------------------------------------------------------------------- dQ
-// Same decomposition as forward, 8 waves: waves w and w+4 own the same 32 query rows and split the K/V tiles
-// (half = w>>2 takes tiles t = 2i + half) through their own double buffers; the two partial dQ^T are added through
-// LDS at the end in a fixed order.  dQ^T[d][q] = scale * sum_key K^T[d][key] dS^T[key][q].
+// Same decomposition as forward: a workgroup takes the j-th heaviest and the j-th lightest 64-row query tile of one
+// (batch, head) -- waves 0-3 the heavy one, waves 4-7 the light one, one of each per SIMD -- over ONE K/V stream; inside
+// a group rb = w&1 is the 32-row block and half = (w>>1)&1 splits the K/V tiles (t = 2i + half) through its own double
+// buffer; the two partial dQ^T of a row block are added through LDS at the end in a fixed order.
+// dQ^T[d][q] = scale * sum_key K^T[d][key] dS^T[key][q].
 __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ Kp,
                                                           const bf16* __restrict__ Vp, const bf16* __restrict__ dO,
                                                           const float* __restrict__ LSE, const float* __restrict__ delta,
@@ -321,11 +331,14 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const bf16* __restrict
                                                           float scale) {
   __shared__ __attribute__((aligned(16))) char smem[8 * TILE];  // 2 halves x 2 stages x (K,V)
   const int lane = lane_id(), w8 = wave_id_uniform();
-  const int half = w8 >> 2, w = w8 & 3;
-  const int qt = gridDim.x - 1 - blockIdx.x;
+  const int grp = w8 >> 2, rb = w8 & 1, half = (w8 >> 1) & 1;
+  const int w = grp * 2 + rb;  // 0..3 inside my half: staging share and merge slot
+  const int n64 = (T + 63) / 64;
+  const int tA = n64 - 1 - (int)blockIdx.x, tB = (int)blockIdx.x;
+  const bool active = grp == 0 || tB != tA;
   const int hq = blockIdx.y, b = blockIdx.z;
   const int hkv = hq / (Hq / Hkv);
-  const int q0 = qt * 128, q0w = q0 + 32 * w;
+  const int q0w = (grp == 0 ? tA : tB) * 64 + 32 * rb;
   const int r = lane & 31, h = lane >> 5;
   const int klen = kv_len ? max(1, min(kv_len[b], T)) : T;
   const long tok0 = (long)b * T;
@@ -351,7 +364,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const bf16* __restrict
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[db][e] = 0.f;
 
-  const int kv_hi = min(q0 + 128, T);
+  const int kv_hi = min(tA * 64 + 64, T);
   const int nkv = (kv_hi + 63) / 64;
   const int nit = (nkv + 1) >> 1;  // trips of both halves; half 1 idles through the last one when nkv is odd
   TileDma kd, vd;
@@ -374,7 +387,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const bf16* __restrict
     const char* vs = ks + TILE;
     cur_i ^= 1;
     const int kv0 = (2 * i + half) * 64;
-    if (kv0 < kv_hi && kv0 <= q0w + 31) {
+    if (active && kv0 < kv_hi && kv0 <= q0w + 31) {
 #pragma unroll
       for (int kb2 = 0; kb2 < 2; ++kb2) {
         f32x16 s, dp;
@@ -412,7 +425,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const bf16* __restrict
       for (int e = 0; e < 16; ++e) xo[(db * 16 + e) * 64 + lane] = acc[db][e];
   }
   __syncthreads();
-  if (half == 1) return;
+  if (half == 1 || !active) return;
 #pragma unroll
   for (int db = 0; db < 4; ++db)
 #pragma unroll
@@ -421,15 +434,18 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const bf16* __restrict
 }
 
 // -------------------------------------------------------------------------------------------- dK, dV
-// grid (ceil(T/128), Hkv, B), 512 threads = 8 waves, two per SIMD.  Waves w and w+4 own the SAME 32 keys
-// k0 + 32w .. +31 of kv head hkv and split every 64-row (Q, dO) tile between them: half = w>>2 takes query rows
-// 32*half .. +31 of each tile.  The block loops over the G query heads of the group and over the 64-row query
-// tiles at or below the diagonal; the two partial (dK^T, dV^T) of a key are added through LDS at the end in a
-// fixed order (no atomics, deterministic).  With ONE wave per SIMD a wave ran its DMA issue, LDS reads, 64 MFMAs
-// and the exp/mask VALU of a tile strictly one after the other (~3.5 us per tile for ~1 us of MFMA, 63 us per
-// launch at B=4,T=512); two independent waves per SIMD overlap those phases.  To fit two waves into the SIMD's 512
-// registers the block's K and V (128 keys) live in LDS instead of registers (64 KiB), beside a 2-stage (Q, dO) ring
-// (64 KiB): waves 0-3 stage K and the Q tiles, waves 4-7 stage V and the dO tiles.
+// grid (ceil(ceil(T/64)/2), Hkv, B), 512 threads = 8 waves, two per SIMD.  Key block kb (64 keys) is seen by the query
+// tiles kb .. ceil(T/64)-1, so the first blocks carry most of the work; a workgroup takes the j-th heaviest and the
+// j-th lightest block (every pair: ceil(T/64)+1 block-tile visits per query head): waves 0-3 the heavy one, waves 4-7
+// the light one, one of each per SIMD.  Inside a group sub = w&1 is the 32-key sub-block a wave owns (the lane owns one
+// key: S = Q K^T with the key on the lane) and rh = (w>>1)&1 the 32-row half of every 64-row (Q, dO) tile it takes.
+// The block loops over the G query heads of the group and over the query tiles at or below the heavy block's
+// diagonal (the light block's waves skip the tiles above theirs); a wave keeps dK^T, dV^T of its keys in registers
+// (dV^T = dO^T P, dK^T = Q^T dS), and the two row halves are added through LDS at the end in a fixed order (no atomics,
+// deterministic).  With ONE wave per SIMD a wave ran its DMA issue, LDS reads, 64 MFMAs and the exp/mask VALU of a
+// tile strictly one after the other; two independent waves per SIMD overlap those phases.  To fit two waves into the
+// SIMD's 512 registers the two blocks' K and V (128 keys) live in LDS instead of registers (64 KiB), beside a 2-stage
+// (Q, dO) ring (64 KiB): waves 0-3 stage K and the Q tiles, waves 4-7 stage V and the dO tiles.
 __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ Kp,
                                                            const bf16* __restrict__ Vp, const bf16* __restrict__ dO,
                                                            const float* __restrict__ LSE, const float* __restrict__ delta,
@@ -437,15 +453,18 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const bf16* __restric
                                                            const int* __restrict__ kv_len, long ldq, long ldk, long ldv,
                                                            long ldo, long lddk, long lddv, int T, int Hq, int Hkv,
                                                            float scale) {
-  // [K 128 rows | V 128 rows | stage 0: Q, dO | stage 1: Q, dO | stat[2 stages][lse2|delta][64 q rows]]
+  // [K: heavy block 64 rows | light block 64 rows][V: same][stage 0: Q, dO | stage 1: Q, dO | stat[2 stages][lse2|delta][64 q rows]]
   // (ONE __shared__ object: a second one beside an LDS-DMA target makes hipcc drain vmcnt before LDS reads)
   __shared__ __attribute__((aligned(16))) char smem[8 * TILE + 1024];
   const int lane = lane_id(), w8 = wave_id_uniform();
-  const int half = w8 >> 2, w = w8 & 3;
+  const int grp = w8 >> 2, sub = w8 & 1, rh = (w8 >> 1) & 1;  // compute role
+  const int sw = w8 & 3;                                       // staging share inside my group of four
   const int hkv = blockIdx.y, b = blockIdx.z;
   const int G = Hq / Hkv;
-  const int k0 = blockIdx.x * 128;  // block 0 sees every query tile: heaviest first
-  const int k0w = k0 + 32 * w;
+  const int n64 = (T + 63) / 64;
+  const int kbA = (int)blockIdx.x, kbB = n64 - 1 - (int)blockIdx.x;  // heavy / light key block
+  const bool active = grp == 0 || kbB != kbA;                       // odd block count: the middle block has no partner
+  const int k0w = (grp == 0 ? kbA : kbB) * 64 + 32 * sub;
   const int r = lane & 31, h = lane >> 5;
   const int klen = kv_len ? max(1, min(kv_len[b], T)) : T;
   const long tok0 = (long)b * T;
@@ -458,10 +477,10 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const bf16* __restric
   float* const stat = (float*)(smem + 8 * TILE);  // [stage][which][64]
   {
     TileDma kvd;
-    kvd.init((half ? Vp + tok0 * ldv : Kp + tok0 * ldk) + hkv * D, half ? ldv : ldk, T, w, lane);
-    char* dst = half ? vsm : ksm;
-    kvd.issue(k0, dst, w);
-    kvd.issue(k0 + 64, dst + TILE, w);
+    kvd.init((grp ? Vp + tok0 * ldv : Kp + tok0 * ldk) + hkv * D, grp ? ldv : ldk, T, sw, lane);
+    char* dst = grp ? vsm : ksm;
+    kvd.issue(kbA * 64, dst, sw);
+    kvd.issue(kbB * 64, dst + TILE, sw);
   }
   f32x16 dk[4], dv[4];
 #pragma unroll
@@ -469,9 +488,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const bf16* __restric
 #pragma unroll
     for (int e = 0; e < 16; ++e) { dk[db][e] = 0.f; dv[db][e] = 0.f; }
 
-  const int qt0 = k0 / 64;             // first 64-row query tile that can see a key of this block
-  const int nqt = (T + 63) / 64;
-  const int per_head = nqt - qt0;
+  const int qt0 = kbA;                 // first 64-row query tile that can see a key of the heavy block
+  const int per_head = n64 - qt0;
   const int nit = G * per_head;
   const int st_i = threadIdx.x & 63, st_which = (threadIdx.x >> 6) & 1;
   // LSE / delta of the 64 query rows of tile `it` (threads 0..127), loaded an iteration before they are written to LDS
@@ -484,15 +502,13 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const bf16* __restric
     const long o = ((long)b * Hq + hq) * T + qq;
     return st_which ? delta[o] : LSE[o] * LOG2E;
   };
-  // one tile = Q rows (waves 0-3) + dO rows (waves 4-7) of query head g, rows qt*64 .. +63; past-the-end: zeros
+  // one tile = Q rows (waves 0-3) + dO rows (waves 4-7) of query head g, rows qt*64 .. +63
   auto stage_it = [&](int it, int buf) {
-    const bool real = it < nit;
-    const int itc = real ? it : nit - 1;
-    const int g = itc / per_head, qt = real ? qt0 + itc % per_head : nqt + 1;
+    const int g = it / per_head, qt = qt0 + it % per_head;
     const int hq = hkv * G + g;
     TileDma d;  // the query head changes with `it`: the descriptor is rebuilt (scalar work only)
-    d.init((half ? dO + tok0 * ldo : Q + tok0 * ldq) + hq * D, half ? ldo : ldq, T, w, lane);
-    d.issue(qt * 64, ring + buf * 2 * TILE + half * TILE, w);
+    d.init((grp ? dO + tok0 * ldo : Q + tok0 * ldq) + hq * D, grp ? ldo : ldq, T, sw, lane);
+    d.issue(qt * 64, ring + buf * 2 * TILE + grp * TILE, sw);
   };
   {
     const float sv0 = load_stat(0);
@@ -510,20 +526,20 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const bf16* __restric
     if (it + 1 < nit) stage_it(it + 1, buf ^ 1);
     const char* qs = ring + buf * 2 * TILE;
     const char* dos = qs + TILE;
-    const int qb0 = (qt0 + it % per_head) * 64 + 32 * half;
-    if (qb0 + 31 < k0w) continue;  // wave-uniform: this wave's 32 query rows are all above its keys
+    const int qb0 = (qt0 + it % per_head) * 64 + 32 * rh;
+    if (!active || qb0 + 31 < k0w) continue;  // wave-uniform: this wave's 32 query rows are all above its keys
     f32x16 s, dp;
 #pragma unroll
     for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
 #pragma unroll
     for (int st = 0; st < 8; ++st) {
-      s = mfma32(row_frag(qs, 32 * half, st, lane), row_frag(ksm, 32 * w, st, lane), s);     // S  = Q K^T (rows q, col key)
-      dp = mfma32(row_frag(dos, 32 * half, st, lane), row_frag(vsm, 32 * w, st, lane), dp);  // dP = dO V^T
+      s = mfma32(row_frag(qs, 32 * rh, st, lane), row_frag(ksm, 64 * grp + 32 * sub, st, lane), s);     // S  = Q K^T
+      dp = mfma32(row_frag(dos, 32 * rh, st, lane), row_frag(vsm, 64 * grp + 32 * sub, st, lane), dp);  // dP = dO V^T
     }
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) {
-      const f32x4 l2 = *(const f32x4*)&stat[buf * 128 + 32 * half + 8 * g4 + 4 * h];
-      const f32x4 dl = *(const f32x4*)&stat[buf * 128 + 64 + 32 * half + 8 * g4 + 4 * h];
+      const f32x4 l2 = *(const f32x4*)&stat[buf * 128 + 32 * rh + 8 * g4 + 4 * h];
+      const f32x4 dl = *(const f32x4*)&stat[buf * 128 + 64 + 32 * rh + 8 * g4 + 4 * h];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int qq = qb0 + 8 * g4 + 4 * h + e;
@@ -537,30 +553,30 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const bf16* __restric
     for (int ss = 0; ss < 2; ++ss) {
       bf16x8 t4[4];
       const bf16x8 pf = acc_frag(s, ss);
-      tr_frag4(dos, 32 * half + 16 * ss, lane, t4);
+      tr_frag4(dos, 32 * rh + 16 * ss, lane, t4);
 #pragma unroll
       for (int db = 0; db < 4; ++db) dv[db] = mfma32(t4[db], pf, dv[db]);  // dV^T += dO^T P
       const bf16x8 df = acc_frag(dp, ss);
-      tr_frag4(qs, 32 * half + 16 * ss, lane, t4);
+      tr_frag4(qs, 32 * rh + 16 * ss, lane, t4);
 #pragma unroll
       for (int db = 0; db < 4; ++db) dk[db] = mfma32(t4[db], df, dk[db]);  // dK^T += Q^T dS
     }
   }
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // drain the tail tile before LDS is reused
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // drain before LDS is reused
   __syncthreads();
-  // merge: half 1 parks dK^T then dV^T of its keys in LDS ([w][slot][lane] floats, 16 KiB per wave and round)
-  float* xo = (float*)smem + (long)w * 64 * 64;
+  // merge: row half 1 parks dK^T then dV^T of its keys in LDS ([slot][reg][lane] floats, 16 KiB per wave and round)
+  float* xo = (float*)smem + (long)(grp * 2 + sub) * 64 * 64;
 #pragma unroll
   for (int round = 0; round < 2; ++round) {
     f32x16* acc = round ? dv : dk;
-    if (half == 1) {
+    if (rh == 1) {
 #pragma unroll
       for (int db = 0; db < 4; ++db)
 #pragma unroll
         for (int e = 0; e < 16; ++e) xo[(db * 16 + e) * 64 + lane] = acc[db][e];
     }
     __syncthreads();
-    if (half == 0) {
+    if (rh == 0) {
 #pragma unroll
       for (int db = 0; db < 4; ++db)
 #pragma unroll
@@ -568,7 +584,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const bf16* __restric
     }
     __syncthreads();
   }
-  if (half == 0) {
+  if (rh == 0 && active) {
     store_tile_rows((char*)xo, dk, scale, dK + (tok0 + k0w) * lddk + hkv * D, lddk, T - k0w, lane);
     store_tile_rows((char*)xo + 8192, dv, 1.f, dV + (tok0 + k0w) * lddv + hkv * D, lddv, T - k0w, lane);
   }
@@ -589,7 +605,7 @@ extern "C" int sd_attn_fwd(const void* q, const void* k, const void* v, void* o,
   if (int e = check_common(B, T, Hq, Hkv, ldq, ldk, ldv, ldo)) return e;
   if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) & 15) return SD_ERR_ALIGN;
   SdProfScope prof(SD_K_ATTN_FWD, 2.0 * B * Hq * (double)T * T * D, (hipStream_t)stream);  // 2 products, causal half
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3((T + 127) / 128, Hq, B), dim3(512), 0, (hipStream_t)stream, (const bf16*)q,
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3(((T + 63) / 64 + 1) / 2, Hq, B), dim3(512), 0, (hipStream_t)stream, (const bf16*)q,
                      (const bf16*)k, (const bf16*)v, (bf16*)o, lse, kv_len, ldq, ldk, ldv, ldo, T, Hq, Hkv, scale);
   SD_CHECK_LAUNCH();
   return 0;
@@ -617,14 +633,14 @@ extern "C" int sd_attn_bwd2(const void* q, const void* k, const void* v, const v
   }
   {
     SdProfScope prof2(SD_K_ATTN_BWD_DQ, 3.0 * B * Hq * (double)T * T * D, sq);  // S, dP (recomputed), dQ
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((T + 127) / 128, Hq, B), dim3(512), 0, sq, (const bf16*)q, (const bf16*)k,
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(((T + 63) / 64 + 1) / 2, Hq, B), dim3(512), 0, sq, (const bf16*)q, (const bf16*)k,
                        (const bf16*)v, (const bf16*)d_o, lse, (const float*)delta, (bf16*)dq, kv_len, ldq, ldk, ldv, ldo,
                        lddq, T, Hq, Hkv, scale);
   }
   SD_CHECK_LAUNCH();
   {
     SdProfScope prof(SD_K_ATTN_BWD_DKV, 4.0 * B * Hq * (double)T * T * D, st);  // S, dP, dV, dK
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((T + 127) / 128, Hkv, B), dim3(512), 0, st, (const bf16*)q,
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(((T + 63) / 64 + 1) / 2, Hkv, B), dim3(512), 0, st, (const bf16*)q,
                        (const bf16*)k, (const bf16*)v, (const bf16*)d_o, lse, (const float*)delta, (bf16*)dk, (bf16*)dv,
                        kv_len, ldq, ldk, ldv, ldo, lddk, lddv, T, Hq, Hkv, scale);
   }
