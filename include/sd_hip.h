@@ -59,6 +59,13 @@ int sd_gemm_bf16_splitk_partial(const void* A, const void* B, void* C, int M, in
                                 int64_t ldc, int trans_a, int trans_b, void* workspace, int64_t workspace_bytes,
                                 int* nsplit_out, void* stream);
 
+/* o-projection dX (autograd of HF:279) with delta = rowsum(dO * O) per (token, head) -- the row constant of the
+ * flash-attention backward (flash_attn, train.py:160,177) -- computed in its epilogue: d_ao [M,Hq*128] = dy [M,H] . Wo,
+ * delta [B,Hq,T] fp32.  Pass the result to sd_attn_bwd2 with o = NULL ("delta is already filled").
+ * SD_ERR_UNSUPPORTED: use sd_gemm_bf16 + sd_attn_bwd2 with o. */
+int sd_gemm_odx_delta(const void* dy, const void* wo, void* d_ao, const void* o, int64_t ldo, float* delta, int M, int T,
+                      int Hq, int H, void* stream);
+
 /* Fused forward GEMMs (fall back to the separate launchers when they return SD_ERR_UNSUPPORTED):
  * sd_gemm_swiglu: act [M,I] = silu(x Wg^T) * (x Wu^T), wgu = [gate rows | up rows] [2I,K]; gu_out [M,2I] nullable (HF:81-83).
  * sd_gemm_qkv_rope: raw q|k|v [M,(Hq+2Hkv)*128] plus RMS-normalised + RoPE-rotated q|k [M,(Hq+Hkv)*128] (HF:252-257). */

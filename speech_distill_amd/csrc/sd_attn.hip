@@ -623,9 +623,11 @@ extern "C" int sd_attn_bwd2(const void* q, const void* k, const void* v, const v
   if (s2 && !(lease.set = sd_lease_events())) return SD_ERR_WORKSPACE;
   hipEvent_t* g_attn_ev = lease.set ? lease.set->ev : nullptr;
   const long total = (long)B * T * Hq;
-  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, st, (const bf16*)d_o,
-                     (const bf16*)o, delta, ldo, T, Hq, total);
-  SD_CHECK_LAUNCH();
+  if (o) {  // o == NULL: `delta` already holds rowsum(dO * O) (sd_gemm_odx_delta)
+    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, st, (const bf16*)d_o,
+                       (const bf16*)o, delta, ldo, T, Hq, total);
+    SD_CHECK_LAUNCH();
+  }
   hipStream_t sq = s2 ? s2 : st;  // stream of the dQ kernel
   if (s2) {
     if (hipEventRecord(g_attn_ev[0], st) != hipSuccess || hipStreamWaitEvent(s2, g_attn_ev[0], 0) != hipSuccess)

@@ -180,7 +180,7 @@ struct EpiArgs {
 template <int EPI, int BM, int NTHR>
 struct EpiPre {
   static constexpr int IT = BM * 16 / NTHR;
-  bf16x8 a[(EPI == 1 || EPI == 4 || EPI == 5) ? IT : 1];
+  bf16x8 a[(EPI == 1 || EPI == 4 || EPI == 5 || EPI == 6) ? IT : 1];
   bf16x8 b[(EPI == 4 || EPI == 5) ? IT : 1];
   bf16x8 gain;
 };
@@ -188,7 +188,7 @@ struct EpiPre {
 template <int EPI, int BM, int NTHR>
 SD_DEV void epi_preload(EpiPre<EPI, BM, NTHR>& pre, const bf16* R, const EpiArgs& ea, int M, int N, long ldr, int m0,
                         int n0, int tn) {
-  if constexpr (EPI == 1 || EPI == 4 || EPI == 5) {
+  if constexpr (EPI == 1 || EPI == 4 || EPI == 5 || EPI == 6) {
 #pragma unroll
     for (int it = 0; it < BM * 16 / NTHR; ++it) {
       const int q = it * NTHR + threadIdx.x;
@@ -198,6 +198,10 @@ SD_DEV void epi_preload(EpiPre<EPI, BM, NTHR>& pre, const bf16* R, const EpiArgs
         const bool ok = gm < M && gn < N;
         bf16x8 z = {};
         pre.a[it] = ok ? *(const bf16x8*)(R + (long)gm * ldr + gn) : z;
+      } else if constexpr (EPI == 6) {  // the attention output O at this (row, 8 columns of head tn)
+        const bool ok = gm < M && gn < N;
+        bf16x8 z = {};
+        pre.a[it] = ok ? *(const bf16x8*)(ea.g0 + (long)gm * ea.ld2 + gn) : z;
       } else if constexpr (EPI == 5) {  // gate and up of the forward at this (row, 8 columns)
         const bool ok = gm < M && gn < N;
         bf16x8 z = {};
@@ -267,6 +271,21 @@ SD_DEV void write_out(const float* cs, bf16* C, const EpiPre<EPI, BM, NTHR>& pre
         }
         *(bf16x8*)(ea.out2 + (long)gm * ea.ld2 + gn) = dg;
         *(bf16x8*)(ea.out2 + (long)gm * ea.ld2 + ea.I + gn) = du;
+      }
+    } else if constexpr (EPI == 6) {
+      // o-projection dX: the tile is d(attention output) of head tn; beside storing it, delta = rowsum(dO * O) of that
+      // head falls out (the 16 threads of a row hold its 128 columns) -- same arithmetic and order as attn_delta_kernel
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
+      if (ok) *(bf16x8*)(C + (long)gm * ldc + gn) = o;
+      float sdel = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sdel += (float)o[e] * (float)pre.a[it][e];
+      sdel += __shfl_xor(sdel, 1, 64); sdel += __shfl_xor(sdel, 2, 64); sdel += __shfl_xor(sdel, 4, 64); sdel += __shfl_xor(sdel, 8, 64);
+      if (oc == 0 && gm < M) {
+        const int bb = gm / ea.T, t = gm - bb * ea.T;
+        ((float*)ea.out2)[((long)bb * ea.Hq + tn) * ea.T + t] = sdel;
       }
     } else if constexpr (EPI == 4) {
       bf16x8 raw;
@@ -1481,6 +1500,7 @@ int launch(const void* A, const void* B, void* C, const void* R, float* slabs, i
   }
   if constexpr (!TA && TB) {
     if (epi_kind == 5) { if (!fast) return SD_ERR_UNSUPPORTED; SD_GEMM_GO(5); SD_CHECK_LAUNCH(); return 0; }
+    if (epi_kind == 6) { if (!fast || splits != 1) return SD_ERR_UNSUPPORTED; SD_GEMM_GO(6); SD_CHECK_LAUNCH(); return 0; }
   }
   if (splits > 1) SD_GEMM_GO(2);
   else if (R) SD_GEMM_GO(1);
@@ -1693,6 +1713,23 @@ extern "C" int sd_gemm_swiglu_bwd(const void* dy, const void* wdown, const void*
   ea.g0 = (const bf16*)gate_up;
   // NN: C[M,I] = dy[M,H] . W[H,I]; C itself (d act) is not written: the epilogue needs a non-null C only for alignment checks
   return dispatch(dy, wdown, dgate_up, nullptr, nullptr, 1, M, I, H, H, I, I, 0, 0, 1, (hipStream_t)stream, 5, &ea);
+}
+
+// o-projection dX with delta = rowsum(dO * O) per (token, head) in its epilogue (the flash-attention backward's row
+// constant; attn_delta_kernel otherwise): d_ao [M, Hq*128] = dy [M,H] . Wo [H, Hq*128]; o = the forward's attention output
+// (row stride ldo); delta [B, Hq, T] fp32, token m = b*T + t.  One 128-column tile is exactly one head.
+extern "C" int sd_gemm_odx_delta(const void* dy, const void* wo, void* d_ao, const void* o, int64_t ldo, float* delta, int M,
+                                 int T, int Hq, int H, void* stream) {
+  if (M <= 0 || T <= 0 || (M % T) || Hq <= 0 || H <= 0 || (H & 7) || (ldo & 7)) return SD_ERR_UNSUPPORTED;
+  if (((uintptr_t)dy | (uintptr_t)wo | (uintptr_t)d_ao | (uintptr_t)o | (uintptr_t)delta) & 15) return SD_ERR_ALIGN;
+  EpiArgs ea{};
+  ea.out2 = (bf16*)delta;
+  ea.g0 = (const bf16*)o;
+  ea.ld2 = ldo;
+  ea.T = T;
+  ea.Hq = Hq;
+  const int QD = Hq * 128;
+  return dispatch(dy, wo, d_ao, nullptr, nullptr, 1, M, QD, H, H, QD, QD, 0, 0, 1, (hipStream_t)stream, 6, &ea);
 }
 
 // gate|up projection with SwiGLU fused into the epilogue (HF:81-83): act [M,I] = silu(x Wg^T) * (x Wu^T);

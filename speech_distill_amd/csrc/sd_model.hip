@@ -318,9 +318,16 @@ extern "C" int sd_qwen3_backward_rows(const sd_qwen3_dims* d, const sd_qwen3_par
              (ovl & 2) ? side_stream : nullptr, s2 ? (void*)g_ev[8] : nullptr);
     if (!grouped) SIGNAL(2);  // dxb final
     // attention
-    RUN(sd_gemm_bf16(dxb, w.wo, b.dao, nullptr, s.M, s.QD, s.h, s.h, s.QD, s.QD, 0, 0, 1, stream));
+    // d(attention output) = dxb . Wo with delta = rowsum(dO * O) in the epilogue (one 128-column tile = one head)
+    const void* o_for_delta = a.ao;
+    {
+      const int rc = sd_gemm_odx_delta(dxb, w.wo, b.dao, a.ao, s.QD, (float*)b.delta, s.M, T, s.Hq, s.h, stream);
+      if (rc == SD_ERR_UNSUPPORTED) RUN(sd_gemm_bf16(dxb, w.wo, b.dao, nullptr, s.M, s.QD, s.h, s.h, s.QD, s.QD, 0, 0, 1, stream));
+      else if (rc) return rc;
+      else o_for_delta = nullptr;
+    }
     if (!grouped) RUN(sd_gemm_bf16(dxb, a.ao, gw.wo, ACC(gw.wo), s.h, s.QD, s.M, s.h, s.QD, s.QD, s.QD, 1, 1, wstream));
-    RUN(sd_attn_bwd2(a.qk, a.qk + (int64_t)s.QD * 2, a.qkv + (int64_t)(s.QD + s.KD) * 2, a.ao, b.dao, (const float*)a.lse,
+    RUN(sd_attn_bwd2(a.qk, a.qk + (int64_t)s.QD * 2, a.qkv + (int64_t)(s.QD + s.KD) * 2, o_for_delta, b.dao, (const float*)a.lse,
                     (float*)b.delta, b.dqk, b.dqk + (int64_t)s.QD * 2, dqkv + (int64_t)(s.QD + s.KD) * 2, kv_len, s.QK,
                     s.QK, s.QKV, s.QD, s.QK, s.QK, s.QKV, B, T, s.Hq, s.Hkv, 128, scale, (ovl & 4) ? side_stream : nullptr, stream));
     RUN(sd_qknorm_rope_bwd2(b.dqk, a.qkv, w.q_gain, w.k_gain, cos_tab, sin_tab, dqkv, batch_gains ? nullptr : gw.q_gain,

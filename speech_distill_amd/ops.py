@@ -161,12 +161,16 @@ def attn_fwd(q, k, v, B, T, Hq, Hkv, kv_len=None):
     return o, lse
 
 
-def attn_bwd(q, k, v, o, do, lse, B, T, Hq, Hkv, kv_len=None):
-    delta = torch.empty_like(lse)
+def attn_bwd(q, k, v, o, do, lse, B, T, Hq, Hkv, kv_len=None, delta=None):
+    """o = None: `delta` already holds rowsum(dO * O) per (batch, head, token) (gemm_odx_delta)."""
+    if o is None and delta is None:
+        raise ValueError("attn_bwd: either o or a precomputed delta")
+    if delta is None:
+        delta = torch.empty_like(lse)
     dq, dk, dv = torch.zeros_like(q), torch.zeros_like(k), torch.zeros_like(v)
-    check(load_lib().sd_attn_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(),
+    check(load_lib().sd_attn_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), _p(o), do.data_ptr(), lse.data_ptr(),
                                  delta.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), _p(kv_len), q.stride(0),
-                                 k.stride(0), v.stride(0), o.stride(0), dq.stride(0), dk.stride(0), dv.stride(0), B, T, Hq,
+                                 k.stride(0), v.stride(0), do.stride(0), dq.stride(0), dk.stride(0), dv.stride(0), B, T, Hq,
                                  Hkv, 128, 128 ** -0.5, _stream()), "sd_attn_bwd")
     return dq, dk, dv
 
@@ -271,6 +275,18 @@ def gemm_swiglu_bwd(dy, wdown, gate_up):
     check(load_lib().sd_gemm_swiglu_bwd(dy.data_ptr(), wdown.data_ptr(), gate_up.data_ptr(), out.data_ptr(), M, I, H,
                                         _stream()), "sd_gemm_swiglu_bwd")
     return out
+
+
+def gemm_odx_delta(dy, wo, o, T, Hq):
+    """d(attention output) [M, Hq*128] = dy [M,H] @ wo [H, Hq*128] and delta [M/T, Hq, T] = rowsum(d_ao * o) per head,
+    the second in the GEMM's epilogue (sd_gemm_odx_delta)."""
+    _need(dy, torch.bfloat16, "dy"), _need(wo, torch.bfloat16, "wo"), _need(o, torch.bfloat16, "o")
+    M, H = dy.shape
+    dao = torch.empty(M, Hq * 128, dtype=torch.bfloat16, device=dy.device)
+    delta = torch.empty(M // T, Hq, T, dtype=torch.float32, device=dy.device)
+    check(load_lib().sd_gemm_odx_delta(dy.data_ptr(), wo.data_ptr(), dao.data_ptr(), o.data_ptr(), o.stride(0),
+                                       delta.data_ptr(), M, T, Hq, H, _stream()), "sd_gemm_odx_delta")
+    return dao, delta
 
 
 class KDLossRowsFn(torch.autograd.Function):

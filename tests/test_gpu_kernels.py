@@ -275,6 +275,31 @@ def test_gemm_grouped_tn_equals_separate_gemms(ops, K):
         assert torch.equal(acc[i], want[i]), (i, float((acc[i].float() - want[i].float()).abs().max()))
 
 
+@pytest.mark.parametrize("M,T,Hq,H", [(2048, 512, 16, 1024), (300, 100, 2, 256)])
+def test_gemm_odx_delta_epilogue(ops, M, T, Hq, H):
+    """o-projection dX with delta = rowsum(dO * O) per (token, head) in the epilogue: d_ao bit-identical to the plain NN
+    GEMM, delta equal to the fp32 row sums of the bf16 products (what attn_delta_kernel computes), ragged M."""
+    g = torch.Generator().manual_seed(M + T)
+    dy = to_dev(bf(torch.randn(M, H, generator=g)))
+    wo = to_dev(bf(torch.randn(H, Hq * 128, generator=g) * 0.05))
+    o = to_dev(bf(torch.randn(M, Hq * 128, generator=g)))
+    dao, delta = ops.gemm_odx_delta(dy, wo, o, T, Hq)
+    ref = ops.gemm(dy, wo, trans_b=True)
+    assert torch.equal(dao, ref)
+    want = (ref.float() * o.float()).view(M // T, T, Hq, 128).sum(-1).permute(0, 2, 1)
+    check_close(f"odx_delta_M{M}", delta, want.double(), 1e-4)
+    # and through the attention backward: delta given (o = None) == delta computed inside
+    B, Hkv = M // T, max(1, Hq // 2)
+    qkv = to_dev(bf(torch.randn(M, (Hq + 2 * Hkv) * 128, generator=g)))
+    q, k, v = qkv[:, :Hq * 128], qkv[:, Hq * 128:(Hq + Hkv) * 128], qkv[:, (Hq + Hkv) * 128:]
+    oo, lse = ops.attn_fwd(q, k, v, B, T, Hq, Hkv)
+    dao2, delta2 = ops.gemm_odx_delta(dy, wo, oo, T, Hq)
+    a = ops.attn_bwd(q, k, v, oo, dao2, lse, B, T, Hq, Hkv)
+    b = ops.attn_bwd(q, k, v, None, dao2, lse, B, T, Hq, Hkv, delta=delta2)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+
+
 def test_gemm_split_k(ops):
     """few tiles + long K -> fp32 slabs + fixed-order reduce (the lm_head dX shape class)."""
     g = torch.Generator().manual_seed(6)
