@@ -118,15 +118,40 @@ __global__ __launch_bounds__(NT) void topk_kernel(const T* __restrict__ X, _Floa
   // ---- pass A: log-sum-exp statistics and per-thread maxima (one HBM read of the row)
   if (threadIdx.x == 0) { n_out = 0; tie_base = 0; }
   float m = -INFINITY, s = 0.f;
-  for (int c = threadIdx.x * 8; c < V; c += NT * 8) {
-    float f[8];
-    load8<T>(x + c, f);
-    float cm = f[0];
+  // Rows of up to MAXCH * NT * 8 elements (the 159 488-entry vocabulary at NT = 512): the maximum of every 8-element
+  // chunk stays in a register, so that pass B re-reads only the chunks that can hold a candidate (~K of 19 936) instead
+  // of the whole row.  Longer rows take the plain loops.
+  constexpr int MAXCH = (NT == 512) ? 40 : (NT == 1024 ? 20 : 0);
+  const bool keep_max = MAXCH > 0 && V <= MAXCH * NT * 8;
+  float cmx[MAXCH > 0 ? MAXCH : 1];
+  if (keep_max) {
 #pragma unroll
-    for (int e = 1; e < 8; ++e) cm = fmaxf(cm, f[e]);
-    if (cm > m) { s *= __expf(m - cm); m = cm; }
+    for (int i = 0; i < MAXCH; ++i) {
+      const int c = (i * NT + (int)threadIdx.x) * 8;
+      cmx[i] = -INFINITY;
+      if (c < V) {
+        float f[8];
+        load8<T>(x + c, f);
+        float cm = f[0];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) s += __expf(f[e] - m);
+        for (int e = 1; e < 8; ++e) cm = fmaxf(cm, f[e]);
+        if (cm > m) { s *= __expf(m - cm); m = cm; }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += __expf(f[e] - m);
+        cmx[i] = cm;
+      }
+    }
+  } else {
+    for (int c = threadIdx.x * 8; c < V; c += NT * 8) {
+      float f[8];
+      load8<T>(x + c, f);
+      float cm = f[0];
+#pragma unroll
+      for (int e = 1; e < 8; ++e) cm = fmaxf(cm, f[e]);
+      if (cm > m) { s *= __expf(m - cm); m = cm; }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += __expf(f[e] - m);
+    }
   }
   tkeys[threadIdx.x] = (m == -INFINITY) ? 0u : f2key(m);
   const float M = block_max<NT>(m, sc);
@@ -155,8 +180,9 @@ __global__ __launch_bounds__(NT) void topk_kernel(const T* __restrict__ X, _Floa
       kth = sel_kth;
     }
     const uint32_t t0 = prefix << (32 - 8 * NPASS);  // low bits zero: a lower bound of the K-th thread max
-    // ---- pass B: gather every element with key >= t0 (row re-read from L2 / Infinity Cache)
-    for (int c = threadIdx.x * 8; c < V; c += NT * 8) {
+    // ---- pass B: gather every element with key >= t0: only the chunks whose maximum reaches t0 are read again
+    // (from L2 / Infinity Cache); rows too long for the register-resident maxima are re-read whole
+    auto gather = [&](int c) {
       float f[8];
       load8<T>(x + c, f);
 #pragma unroll
@@ -167,6 +193,15 @@ __global__ __launch_bounds__(NT) void topk_kernel(const T* __restrict__ X, _Floa
           if (slot < CAP) items[slot] = ((unsigned long long)k << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)(c + e));
         }
       }
+    };
+    if (keep_max) {
+#pragma unroll
+      for (int i = 0; i < MAXCH; ++i) {
+        const int c = (i * NT + (int)threadIdx.x) * 8;
+        if (c < V && f2key(cmx[i]) >= t0) gather(c);
+      }
+    } else {
+      for (int c = threadIdx.x * 8; c < V; c += NT * 8) gather(c);
     }
     __syncthreads();
     const int nc = n_out;
