@@ -25,6 +25,13 @@ struct Sizes {
   }
   int64_t per_layer() const { return 4 * x + 2 * rstd + qkv + qk + ao + lse + gu + act; }
   int64_t tail() const { return 3 * x + rstd; }  // x_last, rstd_f, xn_f, xn_rows (head rows gathered)
+  // activation storage by mode (sd_hip.h SD_SAVE_*): every layer's buffers | L layer inputs + two layer work sets
+  // (recompute; two, because the grouped dW of layer l still reads its set while layer l-1 is recomputed) | one set
+  // + a ping-pong x (inference)
+  int64_t body(int save) const {
+    return save == SD_SAVE_ALL ? (int64_t)L * per_layer() : save == SD_SAVE_LAYER_INPUTS ? (int64_t)L * x + 2 * per_layer()
+                                                                                          : per_layer() + x;
+  }
 };
 
 struct LayerActs {
@@ -84,6 +91,51 @@ struct BwdScratch {
 
 #define RUN(call) do { int e__ = (call); if (e__) return e__; } while (0)
 
+// where layer l's buffers live in `acts` for a training forward (SD_SAVE_ALL / SD_SAVE_LAYER_INPUTS)
+LayerActs layer_acts(const Sizes& s, char* base, int l, int save) {
+  if (save == SD_SAVE_ALL) return carve(s, base + (int64_t)l * s.per_layer());
+  LayerActs a = carve(s, base + (int64_t)s.L * s.x + (int64_t)(l & 1) * s.per_layer());
+  a.x_in = base + (int64_t)l * s.x;
+  return a;
+}
+
+// One decoder layer (HF modeling_qwen3.py:227-250): a.x_in -> x_out, every intermediate into `a`.  x_out == nullptr
+// stops after the SwiGLU (the backward's recompute does not need the layer output again); keep_gu: gate|up is kept
+// for the backward.
+int layer_forward(const sd_qwen3_dims* d, const Sizes& s, const LayerActs& a, const sd_qwen3_layer& w, char* x_out,
+                  bool keep_gu, const int32_t* kv_len, const void* cos_tab, const void* sin_tab, int B, int T,
+                  void* stream) {
+  const float scale = 0.08838834764831845f;  // 128^-1/2
+  RUN(sd_rmsnorm_fwd(a.x_in, w.ln1, a.xn1, (float*)a.rstd1, s.M, s.h, d->eps, stream));
+  // q|k|v projection with q/k-norm + RoPE in the GEMM epilogue (one head = one 128-column tile)
+  int rc = sd_gemm_qkv_rope(a.xn1, w.wqkv, a.qkv, a.qk, w.q_gain, w.k_gain, cos_tab, sin_tab, s.M, T, s.Hq, s.Hkv, s.h,
+                            d->eps, stream);
+  if (rc == SD_ERR_UNSUPPORTED) {
+    RUN(sd_gemm_bf16(a.xn1, w.wqkv, a.qkv, nullptr, s.M, s.QKV, s.h, s.h, s.h, s.QKV, 0, 0, 0, stream));
+    RUN(sd_qknorm_rope_fwd(a.qkv, w.q_gain, w.k_gain, cos_tab, sin_tab, a.qk, s.M, T, s.Hq, s.Hkv, d->eps, stream));
+  } else if (rc) {
+    return rc;
+  }
+  RUN(sd_attn_fwd(a.qk, a.qk + (int64_t)s.QD * 2, a.qkv + (int64_t)(s.QD + s.KD) * 2, a.ao, (float*)a.lse, kv_len,
+                  s.QK, s.QK, s.QKV, s.QD, B, T, s.Hq, s.Hkv, 128, scale, stream));
+  RUN(sd_gemm_bf16(a.ao, w.wo, a.x_mid, a.x_in, s.M, s.h, s.QD, s.QD, s.QD, s.h, s.h, 0, 0, stream));
+  RUN(sd_rmsnorm_fwd(a.x_mid, w.ln2, a.xn2, (float*)a.rstd2, s.M, s.h, d->eps, stream));
+  // gate|up projection: SwiGLU runs in the GEMM epilogue when gate|up need not be kept (no backward follows:
+  // the frozen teacher).  With the 2*I-wide store as well the fused epilogue is no faster than the separate
+  // elementwise pass (tests/bench_fused.py), so the student keeps the two-kernel form.
+  static const int fuse_student = getenv("SD_FUSE_STUDENT_SWIGLU") ? atoi(getenv("SD_FUSE_STUDENT_SWIGLU")) : 0;  // A/B
+  rc = (keep_gu && !fuse_student) ? SD_ERR_UNSUPPORTED
+                                  : sd_gemm_swiglu(a.xn2, w.wgu, keep_gu ? a.gu : nullptr, a.act, s.M, s.I, s.h, stream);
+  if (rc == SD_ERR_UNSUPPORTED) {
+    RUN(sd_gemm_bf16(a.xn2, w.wgu, a.gu, nullptr, s.M, 2 * s.I, s.h, s.h, s.h, 2 * s.I, 0, 0, 0, stream));
+    RUN(sd_swiglu_fwd(a.gu, a.act, s.M, s.I, stream));
+  } else if (rc) {
+    return rc;
+  }
+  if (x_out) RUN(sd_gemm_bf16(a.act, w.wdown, x_out, a.x_mid, s.M, s.h, s.I, s.I, s.I, s.h, s.h, 0, 0, stream));
+  return 0;
+}
+
 }  // namespace
 
 namespace {
@@ -122,8 +174,8 @@ extern "C" int sd_abi_version(void) { return 1; }
 
 extern "C" int64_t sd_qwen3_acts_bytes(const sd_qwen3_dims* d, int B, int T, int save) {
   Sizes s(d, B, T);
-  if (save) return (int64_t)s.L * s.per_layer() + s.tail();
-  return s.per_layer() + s.x + s.tail();  // one layer's buffers + a ping-pong x
+  if (save < SD_SAVE_NONE || save > SD_SAVE_LAYER_INPUTS) return SD_ERR_SHAPE;
+  return s.body(save) + s.tail();
 }
 
 extern "C" int64_t sd_qwen3_bwd_scratch_bytes(const sd_qwen3_dims* d, int B, int T) {
@@ -147,53 +199,25 @@ extern "C" int sd_qwen3_forward_rows(const sd_qwen3_dims* d, const sd_qwen3_para
   if (B <= 0 || T <= 0) return SD_ERR_SHAPE;
   if (head_rows && (n_head_rows <= 0 || n_head_rows > B * T)) return SD_ERR_SHAPE;
   Sizes s(d, B, T);
+  if (save < SD_SAVE_NONE || save > SD_SAVE_LAYER_INPUTS) return SD_ERR_SHAPE;
   if (acts_bytes < sd_qwen3_acts_bytes(d, B, T, save)) return SD_ERR_WORKSPACE;
   char* base = (char*)acts;
-  const float scale = 0.08838834764831845f;  // 128^-1/2
-  char* tail = save ? base + (int64_t)s.L * s.per_layer() : base + s.per_layer() + s.x;
+  char* tail = base + s.body(save);
   char* x_last = tail;
   char* rstd_f = tail + s.x;
   char* xn_f = rstd_f + s.rstd;
   char* xn_rows = xn_f + s.x;
   char* pong = base + s.per_layer();  // inference only
 
-  LayerActs a0 = carve(s, base);
-  RUN(sd_embedding_fwd(ids, p->embed, a0.x_in, s.M, s.h, s.V, stream));
-  char* x_cur = a0.x_in;
+  char* x_cur = save ? layer_acts(s, base, 0, save).x_in : base;
+  RUN(sd_embedding_fwd(ids, p->embed, x_cur, s.M, s.h, s.V, stream));
   for (int l = 0; l < s.L; ++l) {
-    LayerActs a = carve(s, save ? base + (int64_t)l * s.per_layer() : base);
+    LayerActs a = save ? layer_acts(s, base, l, save) : carve(s, base);
     a.x_in = x_cur;
-    const sd_qwen3_layer& w = p->layers_host[l];
     char* x_out;
-    if (save) x_out = (l + 1 < s.L) ? base + (int64_t)(l + 1) * s.per_layer() : x_last;
+    if (save) x_out = (l + 1 < s.L) ? layer_acts(s, base, l + 1, save).x_in : x_last;
     else x_out = (l + 1 < s.L) ? ((x_cur == pong) ? base : pong) : x_last;
-    RUN(sd_rmsnorm_fwd(a.x_in, w.ln1, a.xn1, (float*)a.rstd1, s.M, s.h, d->eps, stream));
-    // q|k|v projection with q/k-norm + RoPE in the GEMM epilogue (one head = one 128-column tile)
-    int rc = sd_gemm_qkv_rope(a.xn1, w.wqkv, a.qkv, a.qk, w.q_gain, w.k_gain, cos_tab, sin_tab, s.M, T, s.Hq, s.Hkv, s.h,
-                              d->eps, stream);
-    if (rc == SD_ERR_UNSUPPORTED) {
-      RUN(sd_gemm_bf16(a.xn1, w.wqkv, a.qkv, nullptr, s.M, s.QKV, s.h, s.h, s.h, s.QKV, 0, 0, 0, stream));
-      RUN(sd_qknorm_rope_fwd(a.qkv, w.q_gain, w.k_gain, cos_tab, sin_tab, a.qk, s.M, T, s.Hq, s.Hkv, d->eps, stream));
-    } else if (rc) {
-      return rc;
-    }
-    RUN(sd_attn_fwd(a.qk, a.qk + (int64_t)s.QD * 2, a.qkv + (int64_t)(s.QD + s.KD) * 2, a.ao, (float*)a.lse, kv_len,
-                    s.QK, s.QK, s.QKV, s.QD, B, T, s.Hq, s.Hkv, 128, scale, stream));
-    RUN(sd_gemm_bf16(a.ao, w.wo, a.x_mid, a.x_in, s.M, s.h, s.QD, s.QD, s.QD, s.h, s.h, 0, 0, stream));
-    RUN(sd_rmsnorm_fwd(a.x_mid, w.ln2, a.xn2, (float*)a.rstd2, s.M, s.h, d->eps, stream));
-    // gate|up projection: SwiGLU runs in the GEMM epilogue when gate|up need not be kept (no backward follows:
-    // the frozen teacher).  With the 2*I-wide store as well the fused epilogue is no faster than the separate
-    // elementwise pass (tests/bench_fused.py), so the student keeps the two-kernel form.
-    static const int fuse_student = getenv("SD_FUSE_STUDENT_SWIGLU") ? atoi(getenv("SD_FUSE_STUDENT_SWIGLU")) : 0;  // A/B
-    rc = (save && !fuse_student) ? SD_ERR_UNSUPPORTED
-                                 : sd_gemm_swiglu(a.xn2, w.wgu, save ? a.gu : nullptr, a.act, s.M, s.I, s.h, stream);
-    if (rc == SD_ERR_UNSUPPORTED) {
-      RUN(sd_gemm_bf16(a.xn2, w.wgu, a.gu, nullptr, s.M, 2 * s.I, s.h, s.h, s.h, 2 * s.I, 0, 0, 0, stream));
-      RUN(sd_swiglu_fwd(a.gu, a.act, s.M, s.I, stream));
-    } else if (rc) {
-      return rc;
-    }
-    RUN(sd_gemm_bf16(a.act, w.wdown, x_out, a.x_mid, s.M, s.h, s.I, s.I, s.I, s.h, s.h, 0, 0, stream));
+    RUN(layer_forward(d, s, a, p->layers_host[l], x_out, save != SD_SAVE_NONE, kv_len, cos_tab, sin_tab, B, T, stream));
     x_cur = x_out;
   }
   RUN(sd_rmsnorm_fwd(x_last, p->final_norm, xn_f, (float*)rstd_f, s.M, s.h, d->eps, stream));
@@ -225,18 +249,22 @@ extern "C" int sd_qwen3_backward_rows(const sd_qwen3_dims* d, const sd_qwen3_par
                                       void* stream) {
   if (d->head_dim != 128) return SD_ERR_UNSUPPORTED;
   if (head_rows && (n_head_rows <= 0 || n_head_rows > B * T)) return SD_ERR_SHAPE;
+  if (B <= 0 || T <= 0 || (accumulate & ~(SD_BWD_ACCUMULATE | SD_BWD_RECOMPUTE))) return SD_ERR_SHAPE;
   Sizes s(d, B, T);
-  if (acts_bytes < sd_qwen3_acts_bytes(d, B, T, 1)) return SD_ERR_WORKSPACE;
+  // SD_BWD_RECOMPUTE: `acts` came from a forward with SD_SAVE_LAYER_INPUTS; each layer's forward is run again from its
+  // saved input right before its backward (the last layer's buffers are still those of the forward itself)
+  const int save = (accumulate & SD_BWD_RECOMPUTE) ? SD_SAVE_LAYER_INPUTS : SD_SAVE_ALL;
+  if (acts_bytes < sd_qwen3_acts_bytes(d, B, T, save)) return SD_ERR_WORKSPACE;
   BwdScratch b(s, (char*)scratch);
   if (scratch_bytes < b.total) return SD_ERR_WORKSPACE;
   char* base = (char*)acts;
   const float scale = 0.08838834764831845f;
-  char* tail = base + (int64_t)s.L * s.per_layer();
+  char* tail = base + s.body(save);
   char* x_last = tail;
   char* rstd_f = tail + s.x;
   char* xn_f = rstd_f + s.rstd;
   char* xn_rows = xn_f + s.x;
-  const int acc = accumulate ? 1 : 0;
+  const int acc = (accumulate & SD_BWD_ACCUMULATE) ? 1 : 0;
 #define ACC(ptr) (acc ? (const void*)(ptr) : (const void*)nullptr)
   // A/B switch for measurements: SD_OVERLAP_MASK bit0 lm_head dW, bit1 gain reduces, bit2 attention dQ, bit3 grouped per-layer dW, bit4 batched per-layer gain reduce (default all on)
   static const int ovl = getenv("SD_OVERLAP_MASK") ? atoi(getenv("SD_OVERLAP_MASK")) : 31;
@@ -290,9 +318,13 @@ extern "C" int sd_qwen3_backward_rows(const sd_qwen3_dims* d, const sd_qwen3_par
     const int P = l & 1;
     char *dx_in = b.dxa[P], *dx_out = (l == 0 && dx0_out) ? (char*)dx0_out : b.dxa[P ^ 1];
     char *dxb = b.dxb[P], *dqkv = b.dqkv[P], *dgu = b.dgu[P];
-    LayerActs a = carve(s, base + (int64_t)l * s.per_layer());
+    const LayerActs a = layer_acts(s, base, l, save);
     const sd_qwen3_layer& w = p->layers_host[l];
     const sd_qwen3_layer& gw = g->layers_host[l];
+    // recompute: this layer's work set was last read by the weight-gradient GEMMs of layer l+2, which `stream` has
+    // already waited for (the `pending` join of layer l+1 below)
+    if (save == SD_SAVE_LAYER_INPUTS && l != s.L - 1)
+      RUN(layer_forward(d, s, a, w, nullptr, true, kv_len, cos_tab, sin_tab, B, T, stream));
     // MLP
     if (!grouped) {
       SIGNAL(0);  // dx_in final

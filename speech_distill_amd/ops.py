@@ -334,6 +334,12 @@ class KDLossRowsFn(torch.autograd.Function):
         return grad, None, None, None, None, None, None, None
 
 
+def left_padded(attention_mask):
+    """0-d bool tensor: some row has a 1 after a 0, i.e. the mask is not a valid-prefix (right-padded) mask."""
+    am = attention_mask != 0
+    return (am[:, 1:] & ~am[:, :-1]).any()
+
+
 def loss_rows(labels, speech_mask=None, right_padded=()):
     """Flat indices b*T+t of the rows the loss reads, and the label each one predicts: position t < T-1 whose
     NEXT label is not -100 (and whose next mask bit is set) -- distillation_loss.py:31-45.  One host read (the
@@ -350,7 +356,6 @@ def loss_rows(labels, speech_mask=None, right_padded=()):
     flat = valid.reshape(-1)
     masks = [m for m in right_padded if m is not None]
     if labels.is_cuda:
-        from .qwen3 import left_padded
         host = torch.stack([flat.sum()] + [left_padded(m.to(labels.device)).to(torch.int64) for m in masks]).tolist()
         if any(host[1:]):
             raise ValueError("attention_mask is not right-padded (a 1 follows a 0): the HIP attention kernels take a "
@@ -360,7 +365,6 @@ def loss_rows(labels, speech_mask=None, right_padded=()):
         except (NotImplementedError, RuntimeError):
             rows = torch.nonzero(flat).reshape(-1)
     else:
-        from .qwen3 import left_padded
         if any(bool(left_padded(m)) for m in masks):
             raise ValueError("attention_mask is not right-padded")
         rows = torch.nonzero(flat).reshape(-1)

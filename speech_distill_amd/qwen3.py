@@ -22,7 +22,7 @@ import torch.nn as nn
 
 from . import _lib
 from ._lib import check, load_lib
-from .ops import _need, _p, _stream, rope_tables
+from .ops import _need, _p, _stream, left_padded, rope_tables  # noqa: F401  (left_padded is re-exported)
 
 
 @dataclass
@@ -63,12 +63,6 @@ class Qwen3Dims:
     @classmethod
     def teacher_17b(cls):  # soulxpodcast/config.py:12-42
         return cls(159488, 2048, 6144, 28, 16, 8)
-
-
-def left_padded(attention_mask):
-    """0-d bool tensor: some row has a 1 after a 0, i.e. the mask is not a valid-prefix (right-padded) mask."""
-    am = attention_mask != 0
-    return (am[:, 1:] & ~am[:, :-1]).any()
 
 
 class _Holder(nn.Module):

@@ -71,17 +71,19 @@ class DistillationTrainer(Trainer):
             self.processing_class.save_pretrained(output_dir)
         torch.save(self.args, os.path.join(output_dir, "training_args.bin"))
 
-    def _teacher_pass(self, inputs, teacher_input_ids, teacher_attention_mask, vocab_size, rows=None):
+    def _teacher_pass(self, inputs, teacher_input_ids, teacher_attention_mask, vocab_size, rows=None, model_kw=None):
         """train.py:60-94: teacher no-grad forward, then on-the-fly top-K unless quantized / top_k <= 0.
-        ``rows``: only those flat rows of the logits are produced (our own teacher) or kept (any other module)."""
+        ``rows``: only those flat rows of the logits are produced (our own teacher) or kept (any other module);
+        ``model_kw``: extra keyword arguments for a HipQwen3ForCausalLM teacher (``padding_checked``)."""
+        model_kw = model_kw or {}
         with torch.no_grad():
             extra = {"logit_rows": rows} if rows is not None and isinstance(self.teacher_model, HipQwen3ForCausalLM) else {}
             if teacher_input_ids is not None:
                 teacher_outputs = self.teacher_model(input_ids=teacher_input_ids, attention_mask=teacher_attention_mask,
-                                                     **extra, **getattr(self, "_teacher_kw", {}))
+                                                     **extra, **model_kw)
             else:
                 teacher_outputs = self.teacher_model(**{k: v for k, v in inputs.items() if k != "labels"}, **extra,
-                                                     **getattr(self, "_teacher_kw", {}))
+                                                     **model_kw)
             teacher_logits = teacher_outputs.logits
             if rows is not None and not extra:
                 teacher_logits = teacher_logits.reshape(-1, teacher_logits.size(-1))[rows]
@@ -116,7 +118,7 @@ class DistillationTrainer(Trainer):
             checked = {"padding_checked": True}
             if rows.numel() == 0:  # N == 0: the full path returns the reference's zeros (distillation_loss.py:47-53)
                 rows = row_labels = None
-        self._teacher_kw = checked if hip_teacher else {}
+        teacher_kw = checked if hip_teacher else {}
         if (need_teacher and self.overlap_teacher and vocab is not None and ids is not None and ids.is_cuda
                 and hip_teacher):
             if self._teacher_stream is None:
@@ -125,7 +127,7 @@ class DistillationTrainer(Trainer):
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 teacher_logits, teacher_top_k_v, teacher_top_k_i = self._teacher_pass(
-                    inputs, teacher_input_ids, teacher_attention_mask, vocab, rows)
+                    inputs, teacher_input_ids, teacher_attention_mask, vocab, rows, teacher_kw)
         elif rows is not None and teacher_top_k_v is not None:  # pre-extracted top-K: keep the same rows
             dev = lab.device
             teacher_top_k_v = teacher_top_k_v.to(dev).reshape(-1, teacher_top_k_v.size(-1))[rows]
@@ -141,7 +143,7 @@ class DistillationTrainer(Trainer):
             teacher_logits_local = teacher_logits
         elif need_teacher:  # reference order: student first, then teacher (train.py:60-94)
             teacher_logits_local, teacher_top_k_v, teacher_top_k_i = self._teacher_pass(
-                inputs, teacher_input_ids, teacher_attention_mask, student_logits.size(-1), rows)
+                inputs, teacher_input_ids, teacher_attention_mask, student_logits.size(-1), rows, teacher_kw)
         teacher_logits = teacher_logits_local
 
         if isinstance(self.distill_loss_fn, DistillationLoss):

@@ -12,7 +12,7 @@ import pytest
 import torch
 
 import speech_distill_amd as sda
-from speech_distill_amd.qwen3 import left_padded
+from speech_distill_amd.ops import left_padded
 
 
 def _tiny(tied=True, seed=0):
