@@ -219,7 +219,18 @@ typedef struct {
   const sd_qwen3_layer* layers_host; /* HOST array of `layers` entries holding DEVICE pointers */
 } sd_qwen3_params;
 
-/* bytes of activation storage for `sd_qwen3_forward`; save_for_backward=0: inference (teacher) */
+/* What a forward keeps in `acts` (the `save_for_backward` argument below):
+ *   SD_SAVE_NONE          inference (the frozen teacher): one layer's buffers + a ping-pong residual stream;
+ *   SD_SAVE_ALL           every activation the backward reads, for all layers (default training mode);
+ *   SD_SAVE_LAYER_INPUTS  layer-granular recompute = what `gradient_checkpointing_enable()` means in HF
+ *                         (train.py:204-208, modeling_qwen3.py decoder-layer checkpointing): only the residual stream
+ *                         entering each layer + two layer work sets; the backward (SD_BWD_RECOMPUTE) runs a layer's
+ *                         forward again right before its backward.  Same kernels on the same inputs, so the
+ *                         gradients are bit-identical to SD_SAVE_ALL. */
+#define SD_SAVE_NONE 0
+#define SD_SAVE_ALL 1
+#define SD_SAVE_LAYER_INPUTS 2
+/* bytes of activation storage for `sd_qwen3_forward` in that mode (negative: SD_ERR_* for an unknown mode) */
 int64_t sd_qwen3_acts_bytes(const sd_qwen3_dims* d, int B, int T, int save_for_backward);
 int64_t sd_qwen3_bwd_scratch_bytes(const sd_qwen3_dims* d, int B, int T);
 
@@ -236,7 +247,8 @@ int sd_qwen3_forward_rows(const sd_qwen3_dims* d, const sd_qwen3_params* p, cons
                           const void* cos_tab, const void* sin_tab, void* acts, int64_t acts_bytes, void* logits,
                           const int64_t* head_rows, int n_head_rows, int B, int T, int save_for_backward, void* stream);
 /* g: same structure as p but holding gradient buffers (bf16, same shapes); dlogits bf16 [B*T,V];
- * accumulate: 0 overwrite grads, 1 add to them (gradient accumulation).
+ * accumulate: bit set of SD_BWD_ACCUMULATE (add to the gradient buffers: gradient accumulation; otherwise overwrite)
+ * and SD_BWD_RECOMPUTE (`acts` was written by a forward with SD_SAVE_LAYER_INPUTS).
  * on_grads_ready (nullable) is called ON THE HOST, from inside this call, each time the kernels that
  * finish one group of gradients have been enqueued on `stream`: stage = SD_STAGE_HEAD (lm_head dW
  * + final norm, before any layer), layer index L-1..0 (that layer's 8 tensors), SD_STAGE_EMBED (the
@@ -250,6 +262,8 @@ int sd_qwen3_forward_rows(const sd_qwen3_dims* d, const sd_qwen3_params* p, cons
  * part of the tied gradient early and exchanges only the B*T touched rows (ddp.py). */
 #define SD_STAGE_HEAD (-1)
 #define SD_STAGE_EMBED (-2)
+#define SD_BWD_ACCUMULATE 1
+#define SD_BWD_RECOMPUTE 2
 typedef void (*sd_stage_cb)(int stage, void* user);
 int sd_qwen3_backward(const sd_qwen3_dims* d, const sd_qwen3_params* p, const sd_qwen3_params* g, const int64_t* ids,
                       const int32_t* kv_len, const void* cos_tab, const void* sin_tab, void* acts, int64_t acts_bytes,

@@ -44,6 +44,9 @@ def parse_args():
     p.add_argument("--ddp_backend", default=None, help="(+) torch.distributed backend (default: nccl = RCCL on ROCm)")
     p.add_argument("--equal_length", action="store_true", help="(+) synthetic samples all max_length long (equal N per rank)")
     p.add_argument("--seed", type=int, default=42)
+    p.add_argument("--recompute", default="auto", choices=["auto", "always", "never"],
+                   help="(+) what gradient checkpointing (on, as in train.py:512-517) does: layer recompute always, never, "
+                        "or only when the activations would take more than a quarter of HBM")
     p.add_argument("--log_json", default=None, help="(+) write trainer.state.log_history there (rank 0; every rank if the "
                    "path contains {rank})")
     return p.parse_args()
@@ -83,7 +86,8 @@ def main():
     torch.cuda.set_device(dev)
     student, teacher = build_models(cfg, dev)
     teacher.eval().requires_grad_(False)               # train.py:165-169
-    student.gradient_checkpointing_enable()            # train.py:204-208 (accepted; activations are kept in HBM)
+    # train.py:204-208; layer-granular recompute only when the policy asks for it ("auto": when HBM would run short)
+    student.gradient_checkpointing_enable(gradient_checkpointing_kwargs={"recompute": cfg.recompute})
     V = student.dims.vocab_size
     bos = cfg.speech_bos_id if cfg.speech_bos_id is not None else (152927 if V > 152928 else V // 2)
     pad = cfg.pad_token_id if cfg.pad_token_id < V else V - 1

@@ -15,6 +15,7 @@ buffers, so a data-parallel all-reduce bucket is a plain slice.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 
 import torch
@@ -83,16 +84,22 @@ class CausalLMOutput(dict):
             raise AttributeError(k) from e
 
 
+SAVE_NONE, SAVE_ALL, SAVE_LAYER_INPUTS = 0, 1, 2  # include/sd_hip.h SD_SAVE_*
+BWD_ACCUMULATE, BWD_RECOMPUTE = 1, 2              # SD_BWD_*
+
+
 class _DecoderFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor, input_ids, kv_len, model, rows):
-        logits, acts = model._run_forward(input_ids, kv_len, save=True, rows=rows)
-        ctx.model, ctx.acts, ctx.ids, ctx.kv_len, ctx.rows = model, acts, input_ids, kv_len, rows
+        save = SAVE_LAYER_INPUTS if model._wants_recompute(*input_ids.shape, input_ids.device) else SAVE_ALL
+        logits, acts = model._run_forward(input_ids, kv_len, save=save, rows=rows)
+        ctx.model, ctx.acts, ctx.ids, ctx.kv_len, ctx.rows, ctx.save = model, acts, input_ids, kv_len, rows, save
         return logits
 
     @staticmethod
     def backward(ctx, dlogits):
-        ctx.model._run_backward(ctx.ids, ctx.kv_len, ctx.acts, dlogits, rows=ctx.rows)
+        ctx.model._run_backward(ctx.ids, ctx.kv_len, ctx.acts, dlogits, rows=ctx.rows,
+                                recompute=ctx.save == SAVE_LAYER_INPUTS)
         ctx.acts = None
         return torch.zeros((), device=dlogits.device), None, None, None, None
 
@@ -105,6 +112,7 @@ class HipQwen3ForCausalLM(nn.Module):
         self.dims = dims
         self.config = config if config is not None else self._hf_config(dims)
         self.gradient_checkpointing = False
+        self.recompute_policy, self.recompute_fraction = "auto", 0.25
         d = dims
         h, I, qd, kd = d.hidden_size, d.intermediate_size, d.q_dim, d.kv_dim
         # ---- flat layout
@@ -310,7 +318,6 @@ class HipQwen3ForCausalLM(nn.Module):
     def save_pretrained(self, save_directory, state_dict=None, safe_serialization=True, **kwargs):
         """HF-loadable checkpoint directory: ``config.json`` (+ ``model.safetensors`` / ``pytorch_model.bin``).
         ``AutoModelForCausalLM.from_pretrained(dir)`` and ``HipQwen3ForCausalLM.from_pretrained(dir)`` both read it."""
-        import os
         os.makedirs(save_directory, exist_ok=True)
         sd = self.state_dict() if state_dict is None else dict(state_dict)
         tied = self._tied_head_key()
@@ -331,7 +338,6 @@ class HipQwen3ForCausalLM(nn.Module):
     def from_pretrained(cls, directory, device="cuda", **kwargs):
         """Build from an HF checkpoint directory (what ``save_pretrained`` above or HF itself wrote); local only."""
         import json
-        import os
         from transformers import AutoConfig
         c = AutoConfig.from_pretrained(directory)
         dims = Qwen3Dims.from_hf_config(c)
@@ -354,13 +360,43 @@ class HipQwen3ForCausalLM(nn.Module):
         return m
 
     # ------------------------------------------------------------------ HF/Trainer protocol no-ops
-    def gradient_checkpointing_enable(self, *a, **k):
-        # train.py:204-208 turns this on by default; with 288 GB of HBM the runner keeps every
-        # activation (2.5 GB at B=4,T=512) instead of recomputing -- the flag is accepted and ignored.
+    def gradient_checkpointing_enable(self, gradient_checkpointing_kwargs=None, **_):
+        """train.py:204-208 / TrainingArguments(gradient_checkpointing=True) (train.py:340), on by default in the reference.
+
+        Checkpointing trades a second forward of every decoder layer for activation memory.  The runner implements it
+        at the same granularity as HF (one decoder layer: only the residual stream entering each layer is kept,
+        ``SD_SAVE_LAYER_INPUTS``), with bit-identical gradients, but WHEN it recomputes is a memory policy, chosen by
+        ``gradient_checkpointing_kwargs={"recompute": ...}`` (or the environment variable ``SD_RECOMPUTE``):
+
+        * ``"auto"`` (default): recompute only when keeping every activation of this batch would take more than
+          ``recompute_fraction`` (default 0.25) of the device's memory -- never at the reference's shapes on 288 GB
+          (2.6 GB at B=4,T=512; 10.4 GB at B=4,T=2048), so the default path pays nothing for the flag;
+        * ``"always"``: what the flag means on a 24-80 GB card (+1 student forward per step, activations / ~9);
+        * ``"never"``.
+        """
+        kw = dict(gradient_checkpointing_kwargs or {})
+        # a later call without the key (HF Trainer calls this again with its own kwargs) keeps an earlier choice
+        policy = kw.get("recompute") or os.environ.get("SD_RECOMPUTE") or self.recompute_policy
+        if policy not in ("auto", "always", "never"):
+            raise ValueError(f"recompute policy {policy!r}: expected 'auto', 'always' or 'never'")
+        self.recompute_policy = policy
+        self.recompute_fraction = float(kw.get("recompute_fraction", self.recompute_fraction))
         self.gradient_checkpointing = True
 
     def gradient_checkpointing_disable(self):
         self.gradient_checkpointing = False
+
+    @property
+    def is_gradient_checkpointing(self):
+        return self.gradient_checkpointing
+
+    def _wants_recompute(self, B, T, device):
+        if not self.gradient_checkpointing or self.recompute_policy == "never":
+            return False
+        if self.recompute_policy == "always":
+            return True
+        full = load_lib().sd_qwen3_acts_bytes(C.byref(self._cdims), B, T, SAVE_ALL)
+        return full > self.recompute_fraction * torch.cuda.get_device_properties(device).total_memory
 
     def enable_input_require_grads(self):
         pass
@@ -405,7 +441,7 @@ class HipQwen3ForCausalLM(nn.Module):
             self._grads_live = True
         return accumulate
 
-    def _run_backward(self, input_ids, kv_len, acts, dlogits, rows=None):
+    def _run_backward(self, input_ids, kv_len, acts, dlogits, rows=None, recompute=False):
         lib = load_lib()
         B, T = input_ids.shape
         accumulate = self._ensure_grads()
@@ -429,7 +465,8 @@ class HipQwen3ForCausalLM(nn.Module):
                                          input_ids.data_ptr(), _p(kv_len), cos.data_ptr(), sin.data_ptr(),
                                          acts.data_ptr(), acts.numel(), dlogits.data_ptr(), _p(rows),
                                          0 if rows is None else rows.numel(), scratch.data_ptr(), sbytes, B, T,
-                                         int(accumulate), _p(dx0), cb, None, self._side_stream_ptr(input_ids.device),
+                                         (BWD_ACCUMULATE if accumulate else 0) | (BWD_RECOMPUTE if recompute else 0),
+                                         _p(dx0), cb, None, self._side_stream_ptr(input_ids.device),
                                          _stream()),
               "sd_qwen3_backward_rows")
         if red is not None:
@@ -466,7 +503,7 @@ class HipQwen3ForCausalLM(nn.Module):
         if torch.is_grad_enabled() and any(p.requires_grad for p in self._params.values()):
             logits = _DecoderFn.apply(self._anchor, ids, kv_len, self, rows)
         else:
-            logits, _ = self._run_forward(ids, kv_len, save=False, rows=rows)
+            logits, _ = self._run_forward(ids, kv_len, save=SAVE_NONE, rows=rows)
         return CausalLMOutput(logits=logits)
 
     def zero_grad(self, set_to_none: bool = True):

@@ -71,3 +71,11 @@ dt = timeit(c4, n=3, w=1)
 f = 3 * flops_per_token(STUDENT_06B, T) + flops_per_token(TEACHER_17B, T)
 print(json.dumps({"config": "C4-shaped step B=4 T=2048 (1 GPU), head on the loss rows, teacher beside the student", "tokens_per_s": B * T / dt, "ms": dt * 1e3,
                   "mfma_frac": B * T / dt * f / 2.5e15}), flush=True)
+
+# the same step with gradient checkpointing taken literally (layer-granular recompute, policy "always")
+student.gradient_checkpointing_enable(gradient_checkpointing_kwargs={"recompute": "always"})
+torch.cuda.synchronize()
+torch.cuda.reset_peak_memory_stats()
+dt2 = timeit(c4, n=3, w=1)
+print(json.dumps({"config": "C4-shaped step, gradient checkpointing = layer recompute", "tokens_per_s": B * T / dt2, "ms": dt2 * 1e3,
+                  "vs_saved_activations": dt2 / dt, "peak_gib": torch.cuda.max_memory_allocated() / 2**30}), flush=True)

@@ -40,6 +40,10 @@ def test_workspace_queries_run_without_gpu():
     train = lib.sd_qwen3_acts_bytes(ctypes.byref(d), 4, 512, 1)
     infer = lib.sd_qwen3_acts_bytes(ctypes.byref(d), 4, 512, 0)
     assert 2e9 < train < 4e9 and infer < train / 10
+    # SD_SAVE_LAYER_INPUTS (gradient checkpointing): 28 layer inputs + two layer work sets instead of 28 sets
+    ckpt = lib.sd_qwen3_acts_bytes(ctypes.byref(d), 4, 512, 2)
+    assert infer < ckpt < train / 8
+    assert lib.sd_qwen3_acts_bytes(ctypes.byref(d), 4, 512, 3) < 0  # unknown mode: SD_ERR_SHAPE, not a size
     assert lib.sd_kdloss_stats_bytes(4, 512) == 4 * 512 * 32
     assert lib.sd_gemm_splitk_plan(2048, 1024, 159488) > 1 and lib.sd_gemm_splitk_plan(2048, 6144, 1024) == 1
 

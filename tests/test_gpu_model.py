@@ -306,6 +306,68 @@ def test_real_width_step_vs_oracle(sda):
         assert abs(gn - rn) <= 8e-2 * rn, (k, gn, rn)
 
 
+@pytest.mark.parametrize("layers", [1, 2, 5])
+def test_gradient_checkpointing_recompute_is_bit_identical(sda, layers):
+    """`gradient_checkpointing_enable()` (train.py:204-208): with the recompute policy "always" the runner keeps only
+    each layer's input and re-runs the layer forward inside backward.  Same kernels on the same inputs: logits and
+    every gradient equal the keep-everything path BIT FOR BIT, also when gradients accumulate over two micro-batches
+    and with right padding; the activation buffer shrinks; "auto" does not recompute at this size."""
+    from speech_distill_amd import DistillationLoss, qwen3 as Q
+    dims = sda.Qwen3Dims(512, 256, 384, layers, 4, 2)
+    model = sda.HipQwen3ForCausalLM(dims, device=dev(), seed=3, init_std=0.05)
+    g = torch.Generator().manual_seed(11)
+    B, T, V = 3, 200, 512
+    batches = []
+    for _ in range(2):
+        ids = torch.randint(0, V, (B, T), generator=g)
+        am = torch.ones(B, T, dtype=torch.long)
+        am[1, T - 37:] = 0
+        labels = ids.clone()
+        labels[am == 0] = -100
+        labels[:, :20] = -100
+        tl = torch.randn(B, T, V, generator=g).bfloat16()
+        batches.append([to_dev(x) for x in (ids, am, labels, tl)])
+    fn = DistillationLoss(2.0, 0.5)
+    seen = []
+    real_forward = model._run_forward
+
+    def spy(input_ids, kv_len, save, rows=None):
+        logits, acts = real_forward(input_ids, kv_len, save, rows=rows)
+        seen.append((int(save), acts.numel()))
+        return logits, acts
+    model._run_forward = spy
+
+    def two_micro_steps():
+        model.zero_grad()
+        out = []
+        for ids, am, labels, tl in batches:
+            logits = model(input_ids=ids, attention_mask=am).logits
+            loss = fn(logits, labels, teacher_logits=tl)[0]
+            loss.backward()
+            out.append((logits.detach().clone(), float(loss)))
+        torch.cuda.synchronize()
+        return out, model.flat_grad.clone()
+
+    ref_out, ref_grad = two_micro_steps()                        # flag off
+    model.gradient_checkpointing_enable()                        # "auto": 288 GB, nothing to save at this size
+    auto_out, auto_grad = two_micro_steps()
+    assert {m for m, _ in seen} == {Q.SAVE_ALL}
+    full_bytes = seen[-1][1]
+    model.gradient_checkpointing_enable(gradient_checkpointing_kwargs={"recompute": "always", "use_reentrant": False})
+    seen.clear()
+    ck_out, ck_grad = two_micro_steps()
+    assert {m for m, _ in seen} == {Q.SAVE_LAYER_INPUTS}
+    if layers >= 5:
+        assert seen[-1][1] < 0.6 * full_bytes
+    for (la, fa), (lb, fb), (lc, fc) in zip(ref_out, auto_out, ck_out):
+        assert fa == fb == fc and torch.equal(la, lb) and torch.equal(la, lc)
+    assert float(ref_grad.float().abs().max()) > 0
+    assert torch.equal(ref_grad, auto_grad) and torch.equal(ref_grad, ck_grad)
+    with pytest.raises(ValueError):
+        model.gradient_checkpointing_enable(gradient_checkpointing_kwargs={"recompute": "sometimes"})
+    record("recompute_bit_identical", layers=layers, full_bytes=full_bytes, ckpt_bytes=seen[-1][1])
+
+
 def test_config4_long_context_step(sda):
     """BASELINE config 4 shapes on one GPU: T=2048 (batch 2), student 0.6B + sparse teacher signal.  Size-independent
     checks: CE ~ ln V at random init, finite gradients, bitwise determinism; and the attention path at T=2048 against

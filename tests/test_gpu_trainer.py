@@ -170,6 +170,21 @@ def test_config4_as_stated_through_the_trainer(sda):
     full = tr.compute_loss(student, dict(batch))
     assert abs(float(full) - res[0][0]) <= 1e-4 * abs(res[0][0]), (float(full), res[0][0])
     assert peak < 200 * 2**30
+    # "grad-checkpointing on" taken literally: layer-granular recompute (policy "always") -- the same loss and the
+    # same gradient bit for bit, from a smaller activation footprint, for one more student forward
+    tr.compact_head = True
+    del full
+    student.gradient_checkpointing_enable(gradient_checkpointing_kwargs={"recompute": "always"})
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
+    student.zero_grad()
+    loss = tr.compute_loss(student, dict(batch))
+    loss.backward()
+    torch.cuda.synchronize()
+    peak_ck = torch.cuda.max_memory_allocated()
+    record("config4_trainer_step_recompute", peak_gib=peak_ck / 2**30, peak_saved_all_gib=peak / 2**30)
+    assert float(loss) == res[0][0] and torch.equal(student.flat_grad, res[0][2])
+    assert peak_ck < peak - 7 * 2**30  # 28 layers x 0.37 GB of activations -> 28 x 17 MB + two work sets
 
 
 def test_config4_real_width_long_context_vs_oracle(sda):
