@@ -159,7 +159,7 @@ def main():
     if args.no_overlap:
         args.serial_teacher = True
         student.overlap_dw = False
-    side = None if args.serial_teacher else torch.cuda.Stream(device=dev)
+    side = None if args.serial_teacher else ops.concurrent_stream(dev, "teacher")  # as DistillationTrainer does
 
     def teacher_topk(rows):
         t_logits = teacher(input_ids=batch["teacher_input_ids"], attention_mask=batch["teacher_attention_mask"],

@@ -276,6 +276,13 @@ int sd_qwen3_backward_rows(const sd_qwen3_dims* d, const sd_qwen3_params* p, con
                            int64_t scratch_bytes, int B, int T, int accumulate, void* dx0_out,
                            sd_stage_cb on_grads_ready, void* cb_user, void* side_stream, void* stream);
 
+/* ---- stream placement.  HIP multiplexes streams onto a few hardware queues (4 by default); streams that share a
+ * queue never overlap.  Measures, with a `spin_us`-long busy-wait kernel on stream_a and an empty one on stream_b,
+ * whether work on b runs while a is busy: *overlap = 1/0.  Synchronises both streams (a calibration call, made once
+ * when the host picks its side streams: teacher beside student (train.py:60-69 vs :54), dW beside dX, RCCL beside
+ * backward). */
+int sd_streams_overlap(void* stream_a, void* stream_b, float spin_us, int* overlap);
+
 /* ---- optional live timing (bench.py): HIP events around every launch, on the launch stream.
  * kinds index the arrays of sd_prof_end; work = algorithmic FLOPs (GEMM, attention) or bytes (others). */
 enum {

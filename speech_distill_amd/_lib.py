@@ -97,6 +97,7 @@ PROTOTYPES = {
     "sd_colsum_reduce_batch": (_i, [_vp, _i, _vp]),
     "sd_sumsq_bf16": (_i, [_vp, _i64, _vp, _vp]),
     "sd_adamw_bf16": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _vp, _f, _vp]),
+    "sd_streams_overlap": (_i, [_vp, _vp, _f, C.POINTER(C.c_int)]),
     "sd_prof_begin": (_i, []),
     "sd_prof_end": (_i, [_vp, _vp, _vp, _i]),
     "sd_prof_symbols": (_i64, [_vp, _i64]),

@@ -61,7 +61,10 @@ class FlatGradAllReduce:
         # RCCL ("nccl"): in-stream all_reduce(AVG) on a dedicated communication stream.  gloo (CPU tests,
         # single-GPU rehearsal): no AVG and no stream semantics -> async SUM, scaled in finish().
         self.cuda = torch.cuda.is_available() and backend == "nccl"
-        self.comm = comm_stream if comm_stream is not None else (torch.cuda.Stream() if self.cuda else None)
+        self.comm = comm_stream
+        if self.comm is None and self.cuda:
+            from . import ops  # a stream measured to overlap the main and the weight-gradient streams (ops.concurrent_stream)
+            self.comm = ops.concurrent_stream(torch.device("cuda", torch.cuda.current_device()), "comm")
         self._works = []
         self.issued = []  # (stage, start, end) actually reduced in the current step (for tests / stats)
         self.stats = {"backwards": 0, "synced": 0}  # backward passes seen / of which communicated

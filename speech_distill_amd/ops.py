@@ -6,6 +6,9 @@ non-zero status to an exception.  CPU tensors are rejected -- there is no fallba
 """
 from __future__ import annotations
 
+import ctypes as C
+import os
+
 import torch
 
 from ._lib import check, load_lib
@@ -19,6 +22,49 @@ def _stream():
 
 def _p(t):
     return 0 if t is None else t.data_ptr()
+
+
+# ---------------------------------------------------------------------------------------------- side streams
+# HIP maps streams onto a few hardware queues (4 by default); two streams on one queue run strictly in turn.  Which
+# streams alias depends on how many the process created before (torch pre-creates pools of 32; torch.distributed and
+# RCCL add their own), so the side streams of the step are chosen by measurement: sd_streams_overlap runs a short
+# busy-wait on one stream and checks that the other is not held up behind it.
+_SIDE_STREAMS = {}  # (device index, role) -> torch.cuda.Stream
+_ROLES_ACTIVE_TOGETHER = {"teacher": (), "dw": ("comm",), "comm": ("dw",)}  # besides the main stream
+
+
+def streams_overlap(a, b, spin_us=200.0):
+    """True when work on stream ``b`` executes while stream ``a`` is busy (they sit on different hardware queues)."""
+    out = C.c_int(0)
+    check(load_lib().sd_streams_overlap(a.cuda_stream, b.cuda_stream, spin_us, C.byref(out)), "sd_streams_overlap")
+    return bool(out.value)
+
+
+def concurrent_stream(device, role):
+    """The process-wide side stream of ``role`` on ``device``: "teacher" (frozen teacher beside the student forward),
+    "dw" (weight-gradient GEMMs beside the dX chain), "comm" (gradient all-reduce beside backward).  Picked once, by
+    experiment, so that it overlaps the current (main) stream and the roles that are busy at the same time; the
+    environment variable SD_STREAM_PICK=0 takes the first stream torch hands out instead."""
+    device = torch.device(device)
+    key = (device.index if device.index is not None else torch.cuda.current_device(), role)
+    if key in _SIDE_STREAMS:
+        return _SIDE_STREAMS[key]
+    with torch.cuda.device(device):
+        main = torch.cuda.current_stream()
+        chosen = torch.cuda.Stream()
+        if os.environ.get("SD_STREAM_PICK", "1") != "0":
+            peers = [_SIDE_STREAMS[(key[0], r)] for r in _ROLES_ACTIVE_TOGETHER[role] if (key[0], r) in _SIDE_STREAMS]
+            fallback = None
+            for _ in range(32):  # torch hands out its pool of 32 streams round-robin
+                if streams_overlap(main, chosen):
+                    if all(streams_overlap(p, chosen) for p in peers):
+                        break
+                    fallback = fallback or chosen
+                chosen = torch.cuda.Stream()
+            else:
+                chosen = fallback or chosen  # no stream clear of every peer: at least clear of the main stream
+    _SIDE_STREAMS[key] = chosen
+    return chosen
 
 
 def _need(t, dtype=None, name="tensor"):
@@ -246,7 +292,6 @@ class KDLossFn(torch.autograd.Function):
 def gemm_grouped_tn(pairs, accumulate_into=None):
     """[(dY [K,M], X [K,N]), ...] (at most 4, common K) -> [dY^T @ X [M,N], ...] in one persistent launch;
     accumulate_into: list of [M,N] tensors to add to in place."""
-    import ctypes as C
     from ._lib import GemmProblem
     n = len(pairs)
     probs = (GemmProblem * n)()
@@ -374,7 +419,6 @@ def loss_rows(labels, speech_mask=None, right_padded=()):
 def colsum_reduce_batch(problems):
     """[(partials [nb, stride] fp32, out [H] bf16, H, accumulate), ...] (at most 8): out[c] (+)= sum_r partials[r, c] for
     every problem in ONE launch (sd_colsum_reduce_batch: a layer's four gain gradients)."""
-    import ctypes as C
     from ._lib import ColsumProblem
     n = len(problems)
     arr = (ColsumProblem * n)()
@@ -411,7 +455,6 @@ def prof_begin():
 
 def prof_end():
     """-> {kind: (total_ms, total_work, launches)} measured with HIP events on the launch stream."""
-    import ctypes as C
     from ._lib import KINDS
     n = len(KINDS)
     ms, work, cnt = (C.c_double * n)(), (C.c_double * n)(), (C.c_int64 * n)()
@@ -421,7 +464,6 @@ def prof_end():
 
 def prof_symbols():
     """-> {kernel symbol: (total_ms, total_work, launches, kind)} of the last prof_end (see sd_prof_symbols)."""
-    import ctypes as C
     from ._lib import KINDS
     lib = load_lib()
     n = lib.sd_prof_symbols(None, 0)
@@ -437,7 +479,6 @@ def prof_symbols():
 def rmsnorm_bwd_from_splitk(a, b_kn, x, w, rstd, dres=None):
     """dx, dw of RMSNorm where dy = a @ b_kn is produced by a split-K GEMM whose fp32 slabs the norm kernel sums
     itself (sd_gemm_bf16_splitk_partial + sd_rmsnorm_bwd_slabs).  Returns (dx, dw, nsplit)."""
-    import ctypes as C
     lib = load_lib()
     M, K = a.shape
     N = b_kn.shape[1]

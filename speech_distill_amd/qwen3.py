@@ -477,7 +477,8 @@ class HipQwen3ForCausalLM(nn.Module):
         if not self.overlap_dw:
             return None
         if self._side_stream is None:
-            self._side_stream = torch.cuda.Stream(device=device)
+            from . import ops
+            self._side_stream = ops.concurrent_stream(device, "dw")
         return self._side_stream.cuda_stream
 
     def forward(self, input_ids=None, attention_mask=None, labels=None, logit_rows=None, **kwargs):

@@ -122,7 +122,7 @@ class DistillationTrainer(Trainer):
         if (need_teacher and self.overlap_teacher and vocab is not None and ids is not None and ids.is_cuda
                 and hip_teacher):
             if self._teacher_stream is None:
-                self._teacher_stream = torch.cuda.Stream(device=ids.device)
+                self._teacher_stream = ops.concurrent_stream(ids.device, "teacher")
             side = self._teacher_stream
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):

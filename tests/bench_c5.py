@@ -53,7 +53,7 @@ labels[:, : T // 4] = -100
 loss_fn = sda.DistillationLoss(2.0, 0.5, inplace_grad=True)
 
 
-side = torch.cuda.Stream(device=dev)
+side = ops.concurrent_stream(dev, "teacher")
 
 
 def c4():  # the sequence of DistillationTrainer.compute_loss on a training step: loss rows only, teacher on a side stream
