@@ -344,6 +344,23 @@ def main():
                     res["roofline"]["traffic_source"] = os.path.relpath(pmc, ROOT) + ": " + t["method"]
             except Exception:
                 pass
+        try:
+            # Not part of the metric (the distillation MICRO-step, repeated gradient_accumulation_steps times per
+            # optimizer step, train.py:336): the fused AdamW + global-norm clip that follows the last micro-step
+            # (HF trainer.py:1778-1796, 2539), measured on the gradients the timed steps left behind, lr = 0.
+            from speech_distill_amd.optim import FlatAdamW
+            opt = FlatAdamW(student, lr=0.0, weight_decay=0.01, clip=1.0)
+            opt.step()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                opt.step()
+            e1.record()
+            torch.cuda.synchronize()
+            res["optimizer_step_ms"] = e0.elapsed_time(e1) / 5
+            del opt
+        except Exception as e:
+            res["optimizer_step_ms"] = repr(e)
         if world == 1 and not args.no_cpu_baseline:
             try:
                 cb, sw, tw, cbatch, cout = cpu_baseline(args.cpu_sample_tokens, min(os.cpu_count() or 1, 16))

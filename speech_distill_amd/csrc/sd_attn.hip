@@ -33,8 +33,9 @@ SD_DEV int f_swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
 // Stage 64 rows of a [*, 128]-column slice (row stride ld) into a 16 KiB LDS tile through a buffer descriptor
 // (buffer_load_dwordx4 ... lds): per-lane offsets are computed once, a tile advance is one scalar offset, rows
 // past the end of the (batch, head) slice read as zeros (they are masked later).
+template <int NP = 4>  // 1 KiB pieces per wave: 4 when four waves stage a tile, 2 when all eight do
 struct TileDma {
-  int voff[4];
+  int voff[NP];
   long row_bytes;
 #if defined(__HIP_DEVICE_COMPILE__)
   __amdgpu_buffer_rsrc_t rsrc;
@@ -46,8 +47,8 @@ struct TileDma {
     rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)g, 0, (int)(((long)(rows - 1) * ld + D) * 2), 0x00020000);
 #endif
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int p = (w * 4 + i) * 64 + lane;
+    for (int i = 0; i < NP; ++i) {
+      const int p = (w * NP + i) * 64 + lane;
       const int row = p >> 4, s = p & 15;
       voff[i] = (int)(((long)row * ld + ((s ^ f_swz(row)) * 8)) * 2);
     }
@@ -56,8 +57,8 @@ struct TileDma {
 #if defined(__HIP_DEVICE_COMPILE__)
     const int soff = (int)(row0 * row_bytes);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (SD_LDS void*)(lds + (w * 4 + i) * 1024), 16, voff[i], soff, 0, 0);
+    for (int i = 0; i < NP; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (SD_LDS void*)(lds + (w * NP + i) * 1024), 16, voff[i], soff, 0, 0);
 #endif
   }
 };
@@ -87,6 +88,26 @@ SD_DEV void tr_frag4(const char* lds, int rb, int lane, bf16x8 (&out)[4]) {
     const int ch = db * 4 + chl;
     lds_tr16_pair_asm(raw[2 * db], raw[2 * db + 1], aA + ((ch ^ sA) << 4), aB + ((ch ^ sB) << 4));
   }
+  lds_tr_wait8(raw);
+#pragma unroll
+  for (int db = 0; db < 4; ++db) out[db] = cat8_u64(raw[2 * db], raw[2 * db + 1]);
+}
+
+// the same reads without the wait: issue now, tr_finish4 later (the latency hides under whatever runs in between)
+SD_DEV void tr_issue4(const char* lds, int rb, int lane, sd_u64 (&raw)[8]) {
+  const int gi = lane >> 4, i = lane & 15, q4 = i >> 2, pp = i & 3;
+  const int rA = rb + 4 * (gi >> 1) + q4, rB = rA + 8;
+  const int sA = f_swz(rA), sB = f_swz(rB);
+  const unsigned base = lds_addr(lds) + 8 * (pp & 1);
+  const unsigned aA = base + rA * 256, aB = base + rB * 256;
+  const int chl = (gi & 1) * 2 + (pp >> 1);
+#pragma unroll
+  for (int db = 0; db < 4; ++db) {
+    const int ch = db * 4 + chl;
+    lds_tr16_pair_asm(raw[2 * db], raw[2 * db + 1], aA + ((ch ^ sA) << 4), aB + ((ch ^ sB) << 4));
+  }
+}
+SD_DEV void tr_finish4(sd_u64 (&raw)[8], bf16x8 (&out)[4]) {
   lds_tr_wait8(raw);
 #pragma unroll
   for (int db = 0; db < 4; ++db) out[db] = cat8_u64(raw[2 * db], raw[2 * db + 1]);
@@ -130,44 +151,110 @@ SD_DEV void store_tile_rows(char* img, const f32x16 (&acc)[4], float mul, bf16* 
   }
 }
 
+// Workgroup -> (pair, head, batch), XCD-aware.  The hardware deals workgroups to the 8 XCDs round-robin by linear id,
+// and every XCD has its own 4 MiB L2.  The `gs` workgroups that stream the same tensors (forward / dQ: the tile pairs of
+// the G query heads of one kv head; dK/dV: the key-block pairs of one kv head) would sit on `gs` different XCDs under the
+// natural numbering, every L2 would pull every K/V stream (8.4 MB at B=4,T=512), and the first tile of a launch took
+// 14 k cycles to arrive.  Here a group is dealt to ONE XCD: id -> (xcd = id % 8, slot = id / 8), group = xcd + 8 *
+// (slot / gs), member = slot % gs (when the number of groups is a multiple of 8; the natural order otherwise).
+struct AttnWg { int pair, member_head, hkv, b; };
+SD_DEV AttnWg attn_wg(int id, int npairs, int heads_per_group, int Hkv, int B) {
+  const int gs = npairs * heads_per_group, ng = Hkv * B;
+  int g, mem;
+  if ((ng & 7) == 0) {
+    const int xcd = id & 7, slot = id >> 3;
+    g = xcd + 8 * (slot / gs);
+    mem = slot % gs;
+  } else {
+    g = id / gs;
+    mem = id % gs;
+  }
+  AttnWg o;
+  o.b = g / Hkv;
+  o.hkv = g % Hkv;
+  o.member_head = mem / npairs;
+  o.pair = mem % npairs;
+  return o;
+}
+
+#ifdef SD_STAMPS
+// DIAGNOSTIC BUILD ONLY (make stamps): s_memtime at the phase boundaries of workgroup (0,0,0) of attn_fwd_kernel,
+// [wave 0..7][point 0..255] (tests/bench_attn_stamps.py)
+#define SD_ATT_STAMP_PARAM , unsigned long long* stamps
+#define ATT_STAMP()                                                                                   \
+  do {                                                                                                \
+    if (stamping && lane == 0 && sidx < 256) stamps[w8 * 256 + sidx] = __builtin_amdgcn_s_memtime();   \
+    ++sidx;                                                                                           \
+  } while (0)
+#define ATT_STAMP_AT(COND, SLOT)                                                                            \
+  do {                                                                                                      \
+    if (stamping && (COND) && lane == 0) stamps[w8 * 256 + (SLOT)] = __builtin_amdgcn_s_memtime();           \
+  } while (0)
+#else
+#define SD_ATT_STAMP_PARAM
+#define ATT_STAMP() do { } while (0)
+#define ATT_STAMP_AT(COND, SLOT) do { } while (0)
+#endif
+
 // ------------------------------------------------------------------------------------------ forward
-// grid (ceil(ceil(T/64)/2), Hq, B), 512 threads.  Under the causal mask a 64-row query tile t sees t+1 K/V tiles, so
+// grid ceil(ceil(T/64)/2) * Hq * B (decoded by attn_wg), 512 threads.  Under the causal mask a 64-row query tile t sees t+1 K/V tiles, so
 // equal row ranges are unequal work (at T = 512: 2, 4, 6, 8 tiles for the four 128-row tiles, and the chip waits for the
 // heaviest).  A workgroup therefore takes a PAIR of 64-row query tiles, the j-th lightest and the j-th heaviest (every
 // pair sees ceil(T/64)+1 tiles in total): waves 0-3 own the heavy tile, waves 4-7 the light one, and since waves w and
 // w+4 share a SIMD every SIMD carries one wave of each.  Both tiles belong to the same (batch, head), so they read the
 // same K/V stream: ONE ring streams the heavy tile's K/V tiles, the light tile's waves use the first of them and then
-// only keep staging.  Inside a group of four: rb = w&1 is the 32-row block, half = (w>>1)&1 splits the K/V tiles
-// (tiles t = 2i + half, each half through its own double buffer, 2 x (K,V) x 2 stages = 64 KiB) -- with one wave per
-// SIMD a wave ran its DMA issue, LDS reads, MFMAs and softmax VALU strictly one after the other; two waves overlap
-// them.  The two partial (m, l, O) states of a row block are merged through LDS at the end (fixed order).
+// only keep staging.  Inside a group of four: rb = w&1 is the 32-row block, half = (w>>1)&1 takes keys 32*half..+31 of
+// EVERY K/V tile, so all eight waves walk one stream in lockstep through a FOUR-stage ring (4 x (K,V) = 128 KiB): three
+// tiles are in flight while one is used.  (Until round 2 the halves took alternate tiles through a double buffer each:
+// one tile ahead is less than the L2 latency with all 256 CUs pulling at once, and an iteration cost 3.2 us at T = 512
+// against 0.85 us of MFMA time.)  With two waves per SIMD the DMA issue, LDS reads, MFMAs and softmax VALU of one wave
+// overlap the other's.  The two partial (m, l, O) states of a row block are merged through LDS at the end (fixed order).
 __global__ __launch_bounds__(512) void attn_fwd_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ Kp,
                                                        const bf16* __restrict__ Vp, bf16* __restrict__ O,
                                                        float* __restrict__ LSE, const int* __restrict__ kv_len, long ldq,
                                                        long ldk, long ldv, long ldo, int T, int Hq, int Hkv,
-                                                       float scale) {
-  __shared__ __attribute__((aligned(16))) char smem[8 * TILE];  // 2 halves x 2 stages x (K,V)
+                                                       float scale SD_ATT_STAMP_PARAM) {
+  __shared__ __attribute__((aligned(16))) char smem[8 * TILE];  // ring of 4 stages x (K,V)
   const int lane = lane_id(), w8 = wave_id_uniform();
+  const int n64 = (T + 63) / 64;
+  const AttnWg wg = attn_wg((int)blockIdx.x, (n64 + 1) / 2, Hq / Hkv, Hkv, (int)gridDim.x / (((n64 + 1) / 2) * Hq));
+#ifdef SD_STAMPS
+  const bool stamping = stamps && wg.pair == 0 && wg.member_head == 0 && wg.hkv == 0 && wg.b == 0;
+  int sidx = 0;
+#endif
+  ATT_STAMP();  // 0: kernel entry
   const int grp = w8 >> 2, rb = w8 & 1, half = (w8 >> 1) & 1;
   const int w = grp * 2 + rb;  // 0..3 inside my half: staging share and merge slot
-  const int n64 = (T + 63) / 64;
-  const int tA = n64 - 1 - (int)blockIdx.x, tB = (int)blockIdx.x;  // heavy / light 64-row query tile of this workgroup
-  const bool active = grp == 0 || tB != tA;                      // odd tile count: the middle tile has no partner
-  const int hq = blockIdx.y, b = blockIdx.z;
-  const int hkv = hq / (Hq / Hkv);
+  const int tA = n64 - 1 - wg.pair, tB = wg.pair;  // heavy / light 64-row query tile of this workgroup
+  const bool active = grp == 0 || tB != tA;      // odd tile count: the middle tile has no partner
+  const int hkv = wg.hkv, b = wg.b;
+  const int hq = hkv * (Hq / Hkv) + wg.member_head;
   const int q0w = (grp == 0 ? tA : tB) * 64 + 32 * rb;
   const int r = lane & 31, h = lane >> 5;
-  const int klen = kv_len ? max(1, min(kv_len[b], T)) : T;
   const long tok0 = (long)b * T;
   const bf16* qb = Q + tok0 * ldq + hq * D;
   const bf16* kb = Kp + tok0 * ldk + hkv * D;
   const bf16* vb = Vp + tok0 * ldv + hkv * D;
 
+  // The K/V stream starts before anything else: the first tiles take ~2 us to arrive (cold TLB / L2), and the Q loads,
+  // the kv_len read and the rest of the set-up fit under that.
+  const int kv_hi = min(tA * 64 + 64, T);  // the heavy tile's diagonal bounds the stream
+  const int nkv = (kv_hi + 63) / 64;
+  TileDma<2> kd, vd;  // all eight waves stage: two 1 KiB pieces of K and of V per wave and tile
+  kd.init(kb, ldk, T, w8, lane);
+  vd.init(vb, ldv, T, w8, lane);
+  // ring of four (K,V) stages; tile i lives in stage i & 3.  Only tile 0 and the Q fragments go out now: the compiler
+  // waits for ALL outstanding loads before the loop (Q lives in registers across it), so anything else issued here
+  // would only delay the first tile.  Tiles 1..3 follow right after the first barrier, tile i+3 when tile i-1 retires.
+  kd.issue(0, smem, w8);
+  vd.issue(0, smem + TILE, w8);
   const int q = q0w + r;  // this lane's query row
   const int qc = q < T ? q : T - 1;
   bf16x8 qf[8];
 #pragma unroll
   for (int st = 0; st < 8; ++st) qf[st] = *(const bf16x8*)(qb + (long)qc * ldq + 16 * st + 8 * h);
+  ATT_STAMP();  // 1: prologue issued
+  const int klen = kv_len ? max(1, min(kv_len[b], T)) : T;
   const int lim = min(q, klen - 1);  // keys > lim are masked for this row
 
   f32x16 o[4];
@@ -178,90 +265,94 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const bf16* __restrict__ 
   float m = NEG, l = 0.f;
   const float c = scale * LOG2E;
 
-  const int kv_hi = min(tA * 64 + 64, T);  // the heavy tile's diagonal bounds the stream
-  const int nkv = (kv_hi + 63) / 64;
-  const int nit = (nkv + 1) >> 1;  // trips of both halves; half 1 idles through the last one when nkv is odd
-  TileDma kd, vd;
-  kd.init(kb, ldk, T, w, lane);
-  vd.init(vb, ldv, T, w, lane);
-  char* ring = smem + half * 4 * TILE;
-  // double buffer per half: tile i+1 is issued while tile i is used.  Tiles past the end are still issued (rows beyond
-  // the slice read as zeros) and never used.
-  kd.issue(half * 64, ring, w);
-  vd.issue(half * 64, ring + TILE, w);
-  int cur_i = 0;
-  for (int i = 0; i < nit; ++i) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();  // my half's tile i has landed; everybody is done reading the other stage
-    asm volatile("" ::: "memory");
-    if ((2 * (i + 1) + half) * 64 < kv_hi) {  // wave-uniform; a tile nobody will read is not fetched (and not waited for)
-      char* nx = ring + (cur_i ^ 1) * 2 * TILE;
-      kd.issue((2 * (i + 1) + half) * 64, nx, w);
-      vd.issue((2 * (i + 1) + half) * 64, nx + TILE, w);
+  auto visible = [&](int i) { const int kv0 = i * 64 + 32 * half; return active && kv0 < kv_hi && kv0 <= q0w + 31; };
+  // One tile = S^T (8 MFMAs, K fragments from LDS) -> online softmax (VALU) -> O^T += V^T P^T (8 MFMAs, transposed V
+  // reads, requested before the softmax so that they are there when it ends).  Measured with the stamp build
+  // (tests/bench_attn_stamps.py): ~1 750 cycles per tile for 512 cycles of MFMA -- the heavy tile's wave is alone on its
+  // SIMD once the light tile's wave has retired, so nothing overlaps its dependent chain.
+  auto tile = [&](int i, const char* ks, const char* vs) {
+    f32x16 s1;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) s1[e] = 0.f;
+#pragma unroll
+    for (int st = 0; st < 8; ++st) s1 = mfma32(row_frag(ks, 32 * half, st, lane), qf[st], s1);
+    ATT_STAMP_AT(i == 3, 201);  // S^T MFMAs issued
+    sd_u64 rv0[8], rv1[8];
+    tr_issue4(vs, 32 * half, lane, rv0);
+    tr_issue4(vs, 32 * half + 16, lane, rv1);
+    const int kv0 = i * 64 + 32 * half;
+    const bool need_mask = (kv0 + 31 > q0w) || (kv0 + 31 >= klen);  // wave-uniform: my keys touch the diagonal / padding
+    float mx = NEG;
+    if (need_mask) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int key = kv0 + acc_row(e, h);
+        const float v = key > lim ? NEG : s1[e];
+        s1[e] = v;
+        mx = fmaxf(mx, v);
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s1[e]);
     }
-    const char* ks = ring + cur_i * 2 * TILE;
-    const char* vs = ks + TILE;
-    cur_i ^= 1;
-    const int kv0 = (2 * i + half) * 64;
-    if (active && kv0 < kv_hi && kv0 <= q0w + 31) {  // wave-uniform: some key of this tile is visible to some row of this wave
-      const bool need_mask = (kv0 + 63 > q0w) || (kv0 + 63 >= klen);  // wave-uniform: tile touches the diagonal / padding
-      f32x16 s[2];
+    ATT_STAMP_AT(i == 3, 202);  // lane maxima (S^T complete)
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    ATT_STAMP_AT(i == 3, 203);  // row maxima
+    const float mn = fmaxf(m, mx);
+    const float alpha = __builtin_amdgcn_exp2f((m - mn) * c);
+    m = mn;
+    float rs = 0.f;
 #pragma unroll
-      for (int kb2 = 0; kb2 < 2; ++kb2) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) s[kb2][e] = 0.f;
-#pragma unroll
-        for (int st = 0; st < 8; ++st) s[kb2] = mfma32(row_frag(ks, kb2 * 32, st, lane), qf[st], s[kb2]);
-      }
-      float mx = NEG;
-      if (need_mask) {
-#pragma unroll
-        for (int kb2 = 0; kb2 < 2; ++kb2)
-#pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            const int key = kv0 + kb2 * 32 + acc_row(e, h);
-            const float v = key > lim ? NEG : s[kb2][e];
-            s[kb2][e] = v;
-            mx = fmaxf(mx, v);
-          }
-      } else {
-#pragma unroll
-        for (int kb2 = 0; kb2 < 2; ++kb2)
-#pragma unroll
-          for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[kb2][e]);
-      }
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float mn = fmaxf(m, mx);
-      const float alpha = __builtin_amdgcn_exp2f((m - mn) * c);
-      m = mn;
-      float rs = 0.f;
-#pragma unroll
-      for (int kb2 = 0; kb2 < 2; ++kb2)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const float p = __builtin_amdgcn_exp2f((s[kb2][e] - mn) * c);
-          s[kb2][e] = p;
-          rs += p;
-        }
-      l = l * alpha + rs;
+    for (int e = 0; e < 16; ++e) {
+      const float p = __builtin_amdgcn_exp2f((s1[e] - mn) * c);
+      s1[e] = p;
+      rs += p;
+    }
+    l = l * alpha + rs;
+    ATT_STAMP_AT(i == 3, 204);  // exponentials
+    if (__any(alpha != 1.f)) {  // the running maximum moved for some row of this wave
 #pragma unroll
       for (int db = 0; db < 4; ++db)
 #pragma unroll
         for (int e = 0; e < 16; ++e) o[db][e] *= alpha;
-#pragma unroll
-      for (int kb2 = 0; kb2 < 2; ++kb2)
-#pragma unroll
-        for (int ss = 0; ss < 2; ++ss) {
-          const bf16x8 pf = acc_frag(s[kb2], ss);
-          bf16x8 vt[4];
-          tr_frag4(vs, kb2 * 32 + 16 * ss, lane, vt);
-#pragma unroll
-          for (int db = 0; db < 4; ++db) o[db] = mfma32(vt[db], pf, o[db]);
-        }
     }
+    ATT_STAMP_AT(i == 3, 205);  // rescaled
+    bf16x8 vt[4];
+    tr_finish4(rv0, vt);  // waits for rv1 too (LDS returns in order)
+    ATT_STAMP_AT(i == 3, 206);  // V^T fragments here
+    const bf16x8 p0 = acc_frag(s1, 0), p1 = acc_frag(s1, 1);
+#pragma unroll
+    for (int db = 0; db < 4; ++db) o[db] = mfma32(vt[db], p0, o[db]);
+#pragma unroll
+    for (int db = 0; db < 4; ++db) o[db] = mfma32(cat8_u64(rv1[2 * db], rv1[2 * db + 1]), p1, o[db]);
+    ATT_STAMP_AT(i == 3, 207);  // P.V MFMAs issued
+  };
+  for (int i = 0; i < nkv; ++i) {
+    // my share of tile i has landed; younger tiles (4 loads each) may still be in flight
+    if (i == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (i + 2 < nkv) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (i + 1 < nkv) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ATT_STAMP();  // 2+4i: my loads of tile i landed
+    __builtin_amdgcn_s_barrier();  // everybody's share of tile i has landed; everybody is done reading tile i-1
+    asm volatile("" ::: "memory");
+    ATT_STAMP();  // 3+4i: barrier passed
+    for (int t = (i == 0 ? 1 : i + 3); t <= i + 3; ++t)  // wave-uniform; 1, 2, 3 after the first barrier
+      if (t < nkv) {
+        char* nx = smem + (t & 3) * 2 * TILE;
+        kd.issue(t * 64, nx, w8);
+        vd.issue(t * 64, nx + TILE, w8);
+      }
+    ATT_STAMP();  // 4+4i: next tile issued
+    if (visible(i)) {
+      ATT_STAMP_AT(i == 3, 200);
+      tile(i, smem + (i & 3) * 2 * TILE, smem + (i & 3) * 2 * TILE + TILE);
+    }
+    ATT_STAMP();  // 5+4i: tile computed (issue side)
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the tail tiles before the ring is reused
   __syncthreads();
+  ATT_STAMP();  // 2+4nkv: loop left, ring free
   // merge the two halves: half 1 parks (m, l, O) in LDS, half 0 combines.  Layout [w][slot][lane] floats.
   float* xo = (float*)smem + (long)w * 66 * 64;
   if (half == 1) {
@@ -289,9 +380,11 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const bf16* __restrict__ 
   const float inv = 1.f / l;
   // every lane of a row has the same `inv` only after the two column halves are combined: lanes r and r+32 hold the
   // same row, and `l` was just summed over them, so scaling per lane before the transposing store is exact
+  ATT_STAMP();  // 2+4nkv+1: merged
   if (!active) return;
   store_tile_rows((char*)xo, o, inv, O + (tok0 + q0w) * ldo + hq * D, ldo, T - q0w, lane);
   if (q < T && h == 0) LSE[((long)b * Hq + hq) * T + q] = m * scale + __logf(l);
+  ATT_STAMP();  // stores issued
 }
 
 // -------------------------------------------------------------------------- delta = rowsum(dO * O)
@@ -334,10 +427,11 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const bf16* __restrict
   const int grp = w8 >> 2, rb = w8 & 1, half = (w8 >> 1) & 1;
   const int w = grp * 2 + rb;  // 0..3 inside my half: staging share and merge slot
   const int n64 = (T + 63) / 64;
-  const int tA = n64 - 1 - (int)blockIdx.x, tB = (int)blockIdx.x;
+  const AttnWg wg = attn_wg((int)blockIdx.x, (n64 + 1) / 2, Hq / Hkv, Hkv, (int)gridDim.x / (((n64 + 1) / 2) * Hq));
+  const int tA = n64 - 1 - wg.pair, tB = wg.pair;
   const bool active = grp == 0 || tB != tA;
-  const int hq = blockIdx.y, b = blockIdx.z;
-  const int hkv = hq / (Hq / Hkv);
+  const int hkv = wg.hkv, b = wg.b;
+  const int hq = hkv * (Hq / Hkv) + wg.member_head;
   const int q0w = (grp == 0 ? tA : tB) * 64 + 32 * rb;
   const int r = lane & 31, h = lane >> 5;
   const int klen = kv_len ? max(1, min(kv_len[b], T)) : T;
@@ -367,7 +461,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const bf16* __restrict
   const int kv_hi = min(tA * 64 + 64, T);
   const int nkv = (kv_hi + 63) / 64;
   const int nit = (nkv + 1) >> 1;  // trips of both halves; half 1 idles through the last one when nkv is odd
-  TileDma kd, vd;
+  TileDma<> kd, vd;
   kd.init(kb, ldk, T, w, lane);
   vd.init(vb, ldv, T, w, lane);
   char* ring = smem + half * 4 * TILE;
@@ -434,7 +528,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const bf16* __restrict
 }
 
 // -------------------------------------------------------------------------------------------- dK, dV
-// grid (ceil(ceil(T/64)/2), Hkv, B), 512 threads = 8 waves, two per SIMD.  Key block kb (64 keys) is seen by the query
+// grid ceil(ceil(T/64)/2) * Hkv * B (decoded by attn_wg), 512 threads = 8 waves, two per SIMD.  Key block kb (64 keys) is seen by the query
 // tiles kb .. ceil(T/64)-1, so the first blocks carry most of the work; a workgroup takes the j-th heaviest and the
 // j-th lightest block (every pair: ceil(T/64)+1 block-tile visits per query head): waves 0-3 the heavy one, waves 4-7
 // the light one, one of each per SIMD.  Inside a group sub = w&1 is the 32-key sub-block a wave owns (the lane owns one
@@ -459,10 +553,11 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const bf16* __restric
   const int lane = lane_id(), w8 = wave_id_uniform();
   const int grp = w8 >> 2, sub = w8 & 1, rh = (w8 >> 1) & 1;  // compute role
   const int sw = w8 & 3;                                       // staging share inside my group of four
-  const int hkv = blockIdx.y, b = blockIdx.z;
   const int G = Hq / Hkv;
   const int n64 = (T + 63) / 64;
-  const int kbA = (int)blockIdx.x, kbB = n64 - 1 - (int)blockIdx.x;  // heavy / light key block
+  const AttnWg wg = attn_wg((int)blockIdx.x, (n64 + 1) / 2, 1, Hkv, (int)gridDim.x / (((n64 + 1) / 2) * Hkv));
+  const int hkv = wg.hkv, b = wg.b;
+  const int kbA = wg.pair, kbB = n64 - 1 - wg.pair;  // heavy / light key block
   const bool active = grp == 0 || kbB != kbA;                       // odd block count: the middle block has no partner
   const int k0w = (grp == 0 ? kbA : kbB) * 64 + 32 * sub;
   const int r = lane & 31, h = lane >> 5;
@@ -476,7 +571,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const bf16* __restric
   char* const ring = smem + 4 * TILE;
   float* const stat = (float*)(smem + 8 * TILE);  // [stage][which][64]
   {
-    TileDma kvd;
+    TileDma<> kvd;
     kvd.init((grp ? Vp + tok0 * ldv : Kp + tok0 * ldk) + hkv * D, grp ? ldv : ldk, T, sw, lane);
     char* dst = grp ? vsm : ksm;
     kvd.issue(kbA * 64, dst, sw);
@@ -506,7 +601,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const bf16* __restric
   auto stage_it = [&](int it, int buf) {
     const int g = it / per_head, qt = qt0 + it % per_head;
     const int hq = hkv * G + g;
-    TileDma d;  // the query head changes with `it`: the descriptor is rebuilt (scalar work only)
+    TileDma<> d;  // the query head changes with `it`: the descriptor is rebuilt (scalar work only)
     d.init((grp ? dO + tok0 * ldo : Q + tok0 * ldq) + hq * D, grp ? ldo : ldq, T, sw, lane);
     d.issue(qt * 64, ring + buf * 2 * TILE + grp * TILE, sw);
   };
@@ -598,6 +693,14 @@ int check_common(int B, int T, int Hq, int Hkv, long ldq, long ldk, long ldv, lo
 
 }  // namespace
 
+#ifdef SD_STAMPS
+static unsigned long long* g_attn_stamps = nullptr;
+extern "C" void sd_debug_attn_stamp_buffer(void* p) { g_attn_stamps = (unsigned long long*)p; }
+#define SD_ATT_STAMP_ARG , g_attn_stamps
+#else
+#define SD_ATT_STAMP_ARG
+#endif
+
 extern "C" int sd_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const int32_t* kv_len,
                            int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int B, int T, int Hq, int Hkv,
                            int head_dim, float scale, void* stream) {
@@ -605,8 +708,8 @@ extern "C" int sd_attn_fwd(const void* q, const void* k, const void* v, void* o,
   if (int e = check_common(B, T, Hq, Hkv, ldq, ldk, ldv, ldo)) return e;
   if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) & 15) return SD_ERR_ALIGN;
   SdProfScope prof(SD_K_ATTN_FWD, 2.0 * B * Hq * (double)T * T * D, (hipStream_t)stream);  // 2 products, causal half
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3(((T + 63) / 64 + 1) / 2, Hq, B), dim3(512), 0, (hipStream_t)stream, (const bf16*)q,
-                     (const bf16*)k, (const bf16*)v, (bf16*)o, lse, kv_len, ldq, ldk, ldv, ldo, T, Hq, Hkv, scale);
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3((((T + 63) / 64 + 1) / 2) * Hq * B), dim3(512), 0, (hipStream_t)stream, (const bf16*)q,
+                     (const bf16*)k, (const bf16*)v, (bf16*)o, lse, kv_len, ldq, ldk, ldv, ldo, T, Hq, Hkv, scale SD_ATT_STAMP_ARG);
   SD_CHECK_LAUNCH();
   return 0;
 }
@@ -635,14 +738,14 @@ extern "C" int sd_attn_bwd2(const void* q, const void* k, const void* v, const v
   }
   {
     SdProfScope prof2(SD_K_ATTN_BWD_DQ, 3.0 * B * Hq * (double)T * T * D, sq);  // S, dP (recomputed), dQ
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(((T + 63) / 64 + 1) / 2, Hq, B), dim3(512), 0, sq, (const bf16*)q, (const bf16*)k,
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((((T + 63) / 64 + 1) / 2) * Hq * B), dim3(512), 0, sq, (const bf16*)q, (const bf16*)k,
                        (const bf16*)v, (const bf16*)d_o, lse, (const float*)delta, (bf16*)dq, kv_len, ldq, ldk, ldv, ldo,
                        lddq, T, Hq, Hkv, scale);
   }
   SD_CHECK_LAUNCH();
   {
     SdProfScope prof(SD_K_ATTN_BWD_DKV, 4.0 * B * Hq * (double)T * T * D, st);  // S, dP, dV, dK
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(((T + 63) / 64 + 1) / 2, Hkv, B), dim3(512), 0, st, (const bf16*)q,
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((((T + 63) / 64 + 1) / 2) * Hkv * B), dim3(512), 0, st, (const bf16*)q,
                        (const bf16*)k, (const bf16*)v, (const bf16*)d_o, lse, (const float*)delta, (bf16*)dk, (bf16*)dv,
                        kv_len, ldq, ldk, ldv, ldo, lddk, lddv, T, Hq, Hkv, scale);
   }
