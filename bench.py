@@ -116,6 +116,9 @@ def main():
     ap.add_argument("--experiment-pipeline", action="store_true",
                     help="MEASUREMENT ONLY (not the reported configuration): issue the NEXT step's teacher pass under this "
                          "step's backward")
+    ap.add_argument("--experiment-cached-rows", action="store_true",
+                    help="MEASUREMENT ONLY (not the reported configuration): select the loss rows once instead of every "
+                         "step -- an upper bound on what the per-step host read of the row count costs")
     ap.add_argument("--no-overlap", action="store_true", help="single stream everywhere (clean per-kernel profiles)")
     args = ap.parse_args()
 
@@ -168,6 +171,7 @@ def main():
 
     phase_ev = []
     pending = []
+    cached_rows = []
 
     def mark():  # 5 event records per step on the current stream (always on: the backward time feeds the JSON line)
         e = torch.cuda.Event(enable_timing=True)
@@ -180,7 +184,11 @@ def main():
         mark()
         rows = row_labels = None
         if not args.full_head:  # rows whose shifted label is not -100 (distillation_loss.py:31-45); one host sync
-            rows, row_labels = ops.loss_rows(batch["labels"])
+            if args.experiment_cached_rows and cached_rows:
+                rows, row_labels = cached_rows[0]  # EXPERIMENT: what the host sync costs (never the reported line)
+            else:
+                rows, row_labels = ops.loss_rows(batch["labels"])
+                cached_rows[:] = [(rows, row_labels)]
         with torch.no_grad():
             if args.experiment_pipeline and overlap and pending:
                 tv, ti = pending.pop()  # EXPERIMENT: issued on the side stream under the previous step's backward
@@ -361,6 +369,10 @@ def main():
             del opt
         except Exception as e:
             res["optimizer_step_ms"] = repr(e)
+        if args.experiment_pipeline or args.experiment_cached_rows:
+            res["experiment"] = "NOT the reported configuration: " + " ".join(
+                f for f, on in (("--experiment-pipeline", args.experiment_pipeline),
+                                ("--experiment-cached-rows", args.experiment_cached_rows)) if on)
         if world == 1 and not args.no_cpu_baseline:
             try:
                 cb, sw, tw, cbatch, cout = cpu_baseline(args.cpu_sample_tokens, min(os.cpu_count() or 1, 16))
