@@ -444,8 +444,11 @@ def test_embedding_fwd_bwd(ops):
 
 
 # -------------------------------------------------------------------------------------- attention
+# the last three: B * Hkv is a multiple of 8, i.e. the XCD-aware workgroup numbering (attn_wg) instead of the natural one,
+# with G = 2 / 1 query heads per kv head, an odd number of tile pairs and a ragged last tile
 @pytest.mark.parametrize("B,T,Hq,Hkv,pad", [(2, 128, 4, 2, False), (1, 200, 2, 1, True), (2, 64, 2, 2, True),
-                                            (1, 512, 4, 2, False), (1, 40, 2, 1, False)])
+                                            (1, 512, 4, 2, False), (1, 40, 2, 1, False), (2, 200, 8, 4, True),
+                                            (3, 72, 8, 8, True), (4, 330, 4, 2, False)])
 def test_attention_fwd_bwd(ops, O, B, T, Hq, Hkv, pad):
     g = torch.Generator().manual_seed(T + Hq)
     M = B * T
