@@ -24,7 +24,8 @@ def parse_args():
     p.add_argument("--dataset_path", default=None)            # train.py:444-449 (load_from_disk directory)
     p.add_argument("--output_dir", default="./student_distilled")
     p.add_argument("--max_length", type=int, default=512)     # train.py:454-456
-    p.add_argument("--epochs", type=int, default=3)
+    p.add_argument("--num_train_epochs", "--epochs", dest="epochs", type=int, default=3)      # train.py:501-503
+    p.add_argument("--warmup_steps", type=int, default=1000)                                   # train.py:504-506
     p.add_argument("--learning_rate", type=float, default=5e-5)
     p.add_argument("--temperature", type=float, default=2.0)  # train.py:488-491
     p.add_argument("--alpha", type=float, default=0.5)        # train.py:492-496
@@ -32,13 +33,43 @@ def parse_args():
     p.add_argument("--per_device_train_batch_size", type=int, default=4)   # (+) hard-coded 4 at train.py:333
     p.add_argument("--gradient_accumulation_steps", type=int, default=4)   # (+) hard-coded 4 at train.py:336
     p.add_argument("--logging_steps", type=int, default=10)                # (+) hard-coded at train.py:338
-    p.add_argument("--pad_token_id", type=int, default=153478)
+    # train.py:507-517: bf16 and gradient checkpointing are on by default in the reference and cannot be switched off
+    # from its command line either (store_true + set_defaults(True)); this path computes in bf16 only
+    p.add_argument("--bf16", action="store_true", default=True)
+    p.add_argument("--gradient_checkpointing", action="store_true", default=True)
+    p.add_argument("--test_size", "--eval_samples", dest="eval_samples", type=int, default=10,
+                   help="held-out samples for the per-epoch evaluation (train.py:518-523, 262-269)")
+    p.add_argument("--report_to", default="none", help="train.py:524-529 (default there: wandb; no network here)")
+    # train.py:530-535 (default there: 1, for on-the-fly tokenisation).  Pre-processed batches collate in microseconds
+    # (vectorised collator), so the default here is the main process; workers are forked AFTER the GPU is initialised
+    p.add_argument("--dataloader_num_workers", type=int, default=0)
+    p.add_argument("--dataloader_prefetch_factor", type=int, default=2)  # train.py:536-541
+    # token strings (train.py:542-577): resolved through the tokenizer found in --student_model; without a tokenizer
+    # directory the two ids the pre-processed path needs are given directly (--pad_token_id / --speech_bos_id)
+    p.add_argument("--speech_bos", default="<|semantic_token_start|>")
+    p.add_argument("--speech_eos", default="<|semantic_token_end|>")
+    p.add_argument("--pad_token", default="<|semantic_token_end|>")
+    p.add_argument("--text_bos", default="<|text_start|>")
+    p.add_argument("--text_eos", default="<|text_end|>")
+    p.add_argument("--text_prefix", default='{"en": "", "zh": "", "yue": "<|Yue|>"}')
+    p.add_argument("--teacher_prefix", default="<|task_podcast|><|SPEAKER_0|>")
+    p.add_argument("--student_prefix", default="")
+    p.add_argument("--pad_token_id", type=int, default=153478, help="(+) when --student_model holds no tokenizer")
     p.add_argument("--speech_bos_id", type=int, default=None, help="(+) id of <|semantic_token_start|> when no tokenizer dir")
+    # train.py:585-594: a quantised teacher switches the trainer to DENSE distillation (train.py:74-79).  Here the
+    # teacher always stays bf16 in HBM (3.5 GB of 288); the flags keep their effect on the loss
+    p.add_argument("--load_teacher_in_4bit", action="store_true")
+    p.add_argument("--load_teacher_in_8bit", action="store_true")
+    # LoRA (train.py:180-202) is a documented user flow outside the hot path: refused loudly
+    p.add_argument("--use_lora", action="store_true")
+    p.add_argument("--lora_r", type=int, default=32)
+    p.add_argument("--lora_alpha", type=int, default=64)
+    p.add_argument("--use_rslora", action="store_true", default=True)
+    p.add_argument("--init_lora_weights", default="pissa")
     p.add_argument("--random_init", action="store_true", help="(+) build teacher/student shapes without weights")
     p.add_argument("--tiny", action="store_true", help="(+) BASELINE config-1-sized models (plumbing runs)")
     p.add_argument("--synthetic_samples", type=int, default=0, help="(+) generate N synthetic pre-processed samples")
     p.add_argument("--max_steps", type=int, default=-1)
-    p.add_argument("--eval_samples", type=int, default=10, help="(+) held-out samples (train.py:262-269 splits off 10)")
     p.add_argument("--save_strategy", default="epoch", help="(+) train.py:341 hard-codes \"epoch\" (with eval per epoch, "
                    "load_best_model_at_end, save_total_limit=3); \"no\" turns checkpoints and evaluation off")
     p.add_argument("--ddp_backend", default=None, help="(+) torch.distributed backend (default: nccl = RCCL on ROCm)")
@@ -88,9 +119,19 @@ def main():
     teacher.eval().requires_grad_(False)               # train.py:165-169
     # train.py:204-208; layer-granular recompute only when the policy asks for it ("auto": when HBM would run short)
     student.gradient_checkpointing_enable(gradient_checkpointing_kwargs={"recompute": cfg.recompute})
+    if cfg.use_lora:
+        raise NotImplementedError("--use_lora (train.py:180-202, PEFT LoRA on the student) is outside the MI355X hot path: "
+                                  "the flat-buffer student trains all parameters")
     V = student.dims.vocab_size
     bos = cfg.speech_bos_id if cfg.speech_bos_id is not None else (152927 if V > 152928 else V // 2)
     pad = cfg.pad_token_id if cfg.pad_token_id < V else V - 1
+    tokenizer = _BosTok(pad, bos)
+    if cfg.student_model and any(os.path.exists(os.path.join(cfg.student_model, f))
+                                 for f in ("tokenizer.json", "tokenizer_config.json", "vocab.json")):
+        from transformers import AutoTokenizer             # train.py:210-231: tokenizer of the student, pad token set
+        tokenizer = AutoTokenizer.from_pretrained(cfg.student_model)
+        tokenizer.pad_token = cfg.pad_token
+        pad, bos = tokenizer.pad_token_id, tokenizer.encode(cfg.speech_bos, add_special_tokens=False)[0]
     if cfg.synthetic_samples:
         g = torch.Generator().manual_seed(1234)        # the same dataset on every rank; the sampler shards it
         rows = []
@@ -117,14 +158,18 @@ def main():
         gradient_accumulation_steps=cfg.gradient_accumulation_steps, num_train_epochs=cfg.epochs,
         learning_rate=cfg.learning_rate, logging_steps=cfg.logging_steps, bf16=True, gradient_checkpointing=True,
         eval_strategy="epoch" if evaluate else "no", save_strategy=cfg.save_strategy,
-        load_best_model_at_end=evaluate and cfg.save_strategy == "epoch", save_total_limit=3, report_to=[],
-        remove_unused_columns=False, label_names=["labels"], max_steps=cfg.max_steps, dataloader_num_workers=0,
-        seed=cfg.seed, **({"ddp_backend": cfg.ddp_backend} if cfg.ddp_backend else {}))     # train.py:331-354
+        load_best_model_at_end=evaluate and cfg.save_strategy == "epoch", save_total_limit=3,
+        report_to=[] if cfg.report_to in ("none", "") else cfg.report_to,
+        remove_unused_columns=False, label_names=["labels"], max_steps=cfg.max_steps, warmup_steps=cfg.warmup_steps,
+        dataloader_num_workers=cfg.dataloader_num_workers,                                  # train.py:348-353
+        dataloader_prefetch_factor=cfg.dataloader_prefetch_factor if cfg.dataloader_num_workers > 0 else None,
+        dataloader_pin_memory=True, seed=cfg.seed, **({"ddp_backend": cfg.ddp_backend} if cfg.ddp_backend else {}))     # train.py:331-354
     # Under torchrun the trainer wraps the student in ddp.HipDataParallel itself (DistillationTrainer._wrap_model):
     # bucketed RCCL all-reduce of the flat gradient under the backward, no_sync on accumulation micro-batches.
     trainer = DistillationTrainer(model=student, args=args, train_dataset=dataset, eval_dataset=eval_dataset,
-                                  data_collator=ProcessedDataCollator(_BosTok(pad, bos), pad_token_id=pad),
-                                  teacher_model=teacher, temperature=cfg.temperature, alpha=cfg.alpha, top_k=cfg.top_k)
+                                  data_collator=ProcessedDataCollator(tokenizer, speech_bos=cfg.speech_bos, pad_token_id=pad),
+                                  teacher_model=teacher, temperature=cfg.temperature, alpha=cfg.alpha, top_k=cfg.top_k,
+                                  is_quantized_teacher=cfg.load_teacher_in_4bit or cfg.load_teacher_in_8bit)
     t0 = time.time()
     trainer.train()                                    # train.py:420
     if trainer.is_world_process_zero():

@@ -42,7 +42,8 @@ def _launch(world, per_device_batch, out, tag):
         cmd = [sys.executable, os.path.join(ROOT, "scripts", "train.py"), "--tiny", "--random_init",
                "--synthetic_samples", "32", "--equal_length", "--max_length", "64", "--top_k", "16",
                "--per_device_train_batch_size", str(per_device_batch), "--gradient_accumulation_steps", "2",
-               "--epochs", "1", "--logging_steps", "1", "--save_strategy", "no", "--learning_rate", "1e-3",
+               "--num_train_epochs", "1", "--logging_steps", "1", "--save_strategy", "no", "--learning_rate", "1e-3",
+               "--warmup_steps", "0",
                "--output_dir", os.path.join(out, tag), "--log_json", os.path.join(out, tag + ".{rank}.json")]
         if world > 1:
             cmd += ["--ddp_backend", "gloo"]

@@ -454,6 +454,54 @@ def test_config5_offline_extraction(sda):
     assert float(same) > 0.9
 
 
+def test_extract_script_end_to_end_on_disk(sda, tmp_path, monkeypatch):
+    """scripts/extract_teacher_logits.py as a user runs it (extract_teacher_logits.py:17-146): an HF checkpoint
+    directory + a pre-processed dataset on disk in, the same dataset with per-sample UNPADDED fp16 / int32
+    ``teacher_top_k_v`` / ``teacher_top_k_i`` columns out (:120-141), in dataset order (shuffle=False, :91).
+    Checked against the fp64-free recipe of the reference computed from the HIP teacher's own logits row by row."""
+    import importlib.util
+    import os
+    import sys
+    from datasets import Dataset, load_from_disk
+    from conftest import ROOT
+    dims = sda.Qwen3Dims(640, 256, 512, 2, 4, 2)
+    teacher = sda.HipQwen3ForCausalLM(dims, device=dev(), seed=21, init_std=0.05)
+    mdir, ddir, odir = (str(tmp_path / n) for n in ("teacher", "data", "out"))
+    teacher.save_pretrained(mdir)
+    g = torch.Generator().manual_seed(5)
+    lens = [37, 64, 9, 50, 64, 23, 41]
+    rows = [{"teacher_input_ids": torch.randint(0, 600, (n,), generator=g).tolist(), "teacher_attention_mask": [1] * n,
+             "student_input_ids": torch.randint(0, 600, (n,), generator=g).tolist(), "student_attention_mask": [1] * n}
+            for n in lens]
+    Dataset.from_list(rows).save_to_disk(ddir)
+    spec = importlib.util.spec_from_file_location("extract_main", os.path.join(ROOT, "scripts", "extract_teacher_logits.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    monkeypatch.setattr(sys, "argv", ["extract_teacher_logits.py", "--teacher_model_path", mdir, "--dataset_path", ddir,
+                                      "--output_path", odir, "--top_k", "16", "--batch_size", "3", "--pad_token_id", "639",
+                                      "--max_length", "60"])
+    mod.main()
+    out = load_from_disk(odir)
+    assert len(out) == len(lens) and {"teacher_top_k_v", "teacher_top_k_i"} <= set(out.column_names)
+    assert out["teacher_input_ids"][2] == rows[2]["teacher_input_ids"]  # order kept, inputs untouched (short row)
+    for r, n in enumerate(lens):
+        n = min(n, 60)  # --max_length
+        v = np.asarray(out[r]["teacher_top_k_v"], dtype=np.float32)
+        i = np.asarray(out[r]["teacher_top_k_i"])
+        assert v.shape == (n, 16) and i.shape == (n, 16), (r, v.shape)
+        ids = torch.tensor([rows[r]["teacher_input_ids"][:n]])
+        with torch.no_grad():
+            lg = teacher(input_ids=to_dev(ids)).logits.float()
+        lp = torch.log_softmax(lg[0], -1).cpu()
+        rv, ri = torch.topk(lp, 16, dim=-1)
+        assert np.abs(v - rv.numpy()).max() <= 1.6e-2, r          # the K largest log-probabilities, in order
+        # every stored index points at an entry with the stored value (bf16 logits of a 640-entry vocabulary tie often,
+        # and the script ran this row inside a padded batch of three: positions may differ only inside such ties)
+        picked = lp.gather(-1, torch.from_numpy(i).long())
+        assert float((picked - torch.from_numpy(v)).abs().max()) <= 1.6e-2, r
+        assert all(len(set(row.tolist())) == 16 for row in i), r    # no index twice
+
+
 def test_flat_adamw_matches_torch_adamw(sda):
     """FlatAdamW (one fused launch, bf16 moments, clip folded in) vs torch.optim.AdamW on fp32 copies + clip_grad_norm_."""
     from speech_distill_amd.optim import FlatAdamW
