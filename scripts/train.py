@@ -148,6 +148,11 @@ def main():
     else:
         from datasets import load_from_disk
         dataset = load_from_disk(cfg.dataset_path)     # train.py:234-236 (pre-processed columns, data.py:124-141)
+        if isinstance(dataset, dict):                  # train.py:243-247: a DatasetDict -> its train split
+            dataset = dataset.get("train", dataset)
+        if not {"student_input_ids", "teacher_input_ids"} <= set(dataset.column_names):   # train.py:253-256
+            raise SystemExit("this path takes PRE-PROCESSED rows (student_input_ids / teacher_input_ids [+ teacher_top_k_v/i]); "
+                             "the on-the-fly DistillDataProcessor of train.py:279-328 is outside the hot path")
         eval_dataset = None
         if cfg.save_strategy != "no":                  # train.py:262-269
             split = dataset.train_test_split(test_size=min(cfg.eval_samples, max(1, len(dataset) // 5)), seed=42)
