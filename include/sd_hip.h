@@ -15,7 +15,10 @@
  *     concurrent backward calls never share an event); (2) the sd_prof_* accumulators (only between
  *     sd_prof_begin/end); (3) measurement switches meant for tests and benchmarks, not for production use:
  *     sd_gemm_force_variant() and the environment variables SD_OVERLAP_MASK, SD_FUSE_STUDENT_SWIGLU, SD_GEMM_NO_P256,
- *     SD_GEMM_P256_MIN_TILES, SD_GEMM_NO_PERSIST, SD_GEMM_GROUP_M, SD_TOPK_NT (A/B switches, each read once);
+ *     SD_GEMM_P256_MIN_TILES, SD_GEMM_NO_PERSIST, SD_GEMM_GROUP_M, SD_TOPK_NT (A/B switches, each read once); (4) one
+ *     2048-float device buffer per GPU holding the per-workgroup partial sums of sd_sumsq_bf16 between its two launches
+ *     (fixed-order reduction: the gradient norm is bit-identical on every data-parallel rank); calls to sd_sumsq_bf16
+ *     on different streams of ONE device must not overlap;
  *   - return value: SD_OK (0), a negative SD_ERR_* code, or a positive hipError_t from the launch.
  */
 #pragma once
@@ -168,6 +171,14 @@ int sd_attn_bwd2(const void* q, const void* k, const void* v, const void* o, con
  * descending, ties to the lowest index; lse_out fp32 [rows] nullable. */
 int sd_logsoftmax_topk(const void* logits, void* top_v, void* top_i, float* lse_out, int rows, int64_t row_stride,
                        int V, int K, int dtype, void* stream);
+
+/* ---- which rows the loss reads (distillation_loss.py:31-45: shift by one, labels != -100, optional speech mask).
+ * labels int64 [B,T]; speech_mask int64 [B,T] nullable; mask_a / mask_b: attention masks int64 [B,T] (nullable) to
+ * validate as valid-prefix (right-padded) masks in the same launch.  rows / row_labels: int64 [B*T] out, the first
+ * meta[0] entries are the flat indices b*T+t in increasing order and the label each row predicts; meta[1] != 0 when a
+ * mask has a 1 after a 0.  meta int32 [2] in device memory (the host reads it once: the row count sizes the lm_heads). */
+int sd_loss_rows(const int64_t* labels, const int64_t* speech_mask, const int64_t* mask_a, const int64_t* mask_b,
+                 int64_t* rows, int64_t* row_labels, int32_t* meta, int B, int T, void* stream);
 
 /* ---- DistillationLoss.forward / backward (distillation_loss.py:14-128).
  * student_logits [B,T,V] (bf16 or fp32 per `dtype`); exactly one of teacher_logits [B,T,V] (dense) or

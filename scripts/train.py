@@ -176,7 +176,14 @@ def main():
                                   teacher_model=teacher, temperature=cfg.temperature, alpha=cfg.alpha, top_k=cfg.top_k,
                                   is_quantized_teacher=cfg.load_teacher_in_4bit or cfg.load_teacher_in_8bit)
     t0 = time.time()
-    trainer.train()                                    # train.py:420
+    if os.environ.get("SD_PROFILE_HOST"):              # (+) where the host spends its time: cProfile, top of cumulative
+        import cProfile
+        import pstats
+        prof = cProfile.Profile()
+        prof.runcall(trainer.train)
+        pstats.Stats(prof).sort_stats("cumulative").print_stats(45)
+    else:
+        trainer.train()                                # train.py:420
     if trainer.is_world_process_zero():
         print(f"done in {time.time() - t0:.1f}s; log tail: {trainer.state.log_history[-3:]}")
     if cfg.log_json and (trainer.is_world_process_zero() or "{rank}" in cfg.log_json):
@@ -185,6 +192,7 @@ def main():
         with open(cfg.log_json.replace("{rank}", os.environ.get("RANK", "0")), "w") as f:
             json.dump({"log_history": trainer.state.log_history, "best_model_checkpoint": trainer.state.best_model_checkpoint,
                        "world_size": int(os.environ.get("WORLD_SIZE", 1)), "wrapped": type(trainer.model_wrapped).__name__,
+                       "optimizer": type(getattr(trainer.optimizer, "optimizer", trainer.optimizer)).__name__,
                        "reducer": None if red is None else red.stats, "global_step": trainer.state.global_step,
                        "param_checksum": float(student.flat.double().sum())}, f)
 

@@ -92,6 +92,7 @@ PROTOTYPES = {
     "sd_kdloss_fwd_rows": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _vp]),
     "sd_kdloss_bwd_rows": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _vp]),
     "sd_rows_scatter": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    "sd_loss_rows": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "sd_rmsnorm_bwd_partial_rows": (_i, [_i, _i]),
     "sd_qknorm_rope_bwd_partial_rows": (_i, [_i, _i, _i]),
     "sd_colsum_reduce_batch": (_i, [_vp, _i, _vp]),

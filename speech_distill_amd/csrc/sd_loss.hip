@@ -369,3 +369,80 @@ extern "C" int sd_kdloss_bwd(const void* student_logits, const void* teacher_log
   return run_bwd<float>(student_logits, teacher_logits, top_k_v, top_k_i, labels, row_stats, loss_out, grad_total,
                         grad_logits, B, T, V, K, temperature, alpha, (hipStream_t)stream);
 }
+
+// ---------------------------------------------------------------------------------------- loss rows
+// distillation_loss.py:31-45: the loss reads position t of sequence b iff t < T-1, labels[b][t+1] != -100 and (with a
+// speech mask) speech_mask[b][t+1] != 0.  One workgroup compacts the flat indices b*T+t of those rows IN ORDER (ballot
+// prefix inside a wave, wave totals through LDS), writes the label each one predicts, and checks that the attention
+// masks are valid-prefix (right-padded) masks -- everything the host needs before it can size the lm_head GEMMs, in one
+// launch and one 8-byte read instead of ~15 tiny torch kernels.
+namespace {
+
+__global__ __launch_bounds__(1024) void loss_rows_kernel(const long long* __restrict__ labels,
+                                                         const long long* __restrict__ speech_mask,
+                                                         const long long* __restrict__ mask_a,
+                                                         const long long* __restrict__ mask_b, long long* __restrict__ rows,
+                                                         long long* __restrict__ row_labels, int* __restrict__ meta, int B,
+                                                         int T) {
+  __shared__ int wave_tot[16];
+  __shared__ int base_s, bad_s;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (tid == 0) { base_s = 0; bad_s = 0; }
+  __syncthreads();
+  const long n = (long)B * T;
+  int bad = 0;
+  for (long c0 = 0; c0 < n; c0 += 1024) {
+    const long e = c0 + tid;
+    bool valid = false;
+    long long lab = -100;
+    if (e < n) {
+      const int t = (int)(e % T);
+      if (t + 1 < T) {
+        lab = labels[e + 1];
+        valid = lab != -100 && (!speech_mask || speech_mask[e + 1] != 0);
+      }
+      if (t > 0) {
+        if (mask_a && mask_a[e] != 0 && mask_a[e - 1] == 0) bad = 1;
+        if (mask_b && mask_b[e] != 0 && mask_b[e - 1] == 0) bad = 1;
+      }
+    }
+    const unsigned long long bal = __ballot(valid);
+    const int before = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_tot[wv] = __popcll(bal);
+    __syncthreads();
+    int off = base_s;
+    for (int w = 0; w < wv; ++w) off += wave_tot[w];
+    if (valid) {
+      rows[off + before] = e;
+      row_labels[off + before] = lab;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int tot = 0;
+      for (int w = 0; w < 16; ++w) tot += wave_tot[w];
+      base_s += tot;
+    }
+    __syncthreads();
+  }
+  if (bad) atomicOr(&bad_s, 1);
+  __syncthreads();
+  if (tid == 0) {
+    meta[0] = base_s;
+    meta[1] = bad_s;
+  }
+}
+
+}  // namespace
+
+extern "C" int sd_loss_rows(const int64_t* labels, const int64_t* speech_mask, const int64_t* mask_a, const int64_t* mask_b,
+                            int64_t* rows, int64_t* row_labels, int32_t* meta, int B, int T, void* stream) {
+  if (B <= 0 || T <= 0 || (long)B * T > (1l << 30)) return SD_ERR_SHAPE;
+  if (!labels || !rows || !row_labels || !meta) return SD_ERR_SHAPE;
+  SD_PROF_LABEL("loss_rows B=%d T=%d", B, T);
+  SdProfScope prof(SD_K_MISC, 8.0 * B * T, (hipStream_t)stream);
+  hipLaunchKernelGGL(loss_rows_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const long long*)labels,
+                     (const long long*)speech_mask, (const long long*)mask_a, (const long long*)mask_b, (long long*)rows,
+                     (long long*)row_labels, meta, B, T);
+  SD_CHECK_LAUNCH();
+  return 0;
+}

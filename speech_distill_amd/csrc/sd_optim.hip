@@ -8,6 +8,21 @@
 
 namespace {
 
+// Per-workgroup partial sums of sd_sumsq_bf16, combined by a second launch in a fixed order: the norm must come out
+// bit-identical on every data-parallel rank (it scales the update, and ranks that round it differently drift apart --
+// seen as different parameter checksums on two ranks when the partials were combined with atomicAdd).  One buffer per
+// device (the code object is loaded per device); two sd_sumsq_bf16 calls in flight on different streams of one device
+// would share it -- the optimizer step has no such concurrency.
+__device__ float g_sumsq_partials[2048];
+
+__global__ __launch_bounds__(256) void sumsq_final_kernel(int nb, float* out) {
+  __shared__ float sc[32];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < nb; i += 256) s += g_sumsq_partials[i];
+  s = block_sum<256>(s, sc);
+  if (threadIdx.x == 0) out[0] += s;
+}
+
 __global__ __launch_bounds__(256) void sumsq_kernel(const bf16* __restrict__ x, long n8, long n, float* out) {
   __shared__ float sc[32];
   float s = 0.f;
@@ -19,7 +34,7 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const bf16* __restrict__ x, 
   if (blockIdx.x == 0)
     for (long i = n8 * 8 + threadIdx.x; i < n; i += 256) { const float f = (float)x[i]; s += f * f; }
   s = block_sum<256>(s, sc);
-  if (threadIdx.x == 0) atomicAdd(out, s);
+  if (threadIdx.x == 0) g_sumsq_partials[blockIdx.x] = s;
 }
 
 SD_DEV void adam1(float& p, float g, float& m, float& v, float lr, float b1, float b2, float eps, float wd, float bc1,
@@ -65,8 +80,10 @@ extern "C" int sd_sumsq_bf16(const void* x, int64_t n, float* out_accum, void* s
   if ((uintptr_t)x & 15) return SD_ERR_ALIGN;
   const long n8 = n / 8;
   const int nb = (int)((n8 + 255) / 256 < 2048 ? (n8 + 255) / 256 : 2048);
-  hipLaunchKernelGGL(sumsq_kernel, dim3(nb < 1 ? 1 : nb), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, n8, (long)n,
-                     out_accum);
+  const int grid = nb < 1 ? 1 : nb;
+  hipLaunchKernelGGL(sumsq_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, n8, (long)n, out_accum);
+  SD_CHECK_LAUNCH();
+  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, grid, out_accum);
   SD_CHECK_LAUNCH();
   return 0;
 }

@@ -391,6 +391,24 @@ def loss_rows(labels, speech_mask=None, right_padded=()):
     row count sizes the lm_head GEMMs); ``right_padded``: attention masks to validate in that same read -- raises
     ValueError if one of them is not a valid-prefix mask (see HipQwen3ForCausalLM.forward)."""
     B, T = labels.shape
+    masks = [m for m in right_padded if m is not None]
+    if labels.is_cuda and len(masks) <= 2:  # one launch (sd_loss_rows) + one 8-byte read
+        def i64(t):
+            t = t.to(labels.device)
+            return (t if t.dtype == torch.int64 else (t != 0).to(torch.int64)).contiguous()
+        lab = i64(labels)
+        keep = [lab] + [i64(m) for m in masks] + ([i64(speech_mask)] if speech_mask is not None else [])
+        rows = torch.empty(B * T, dtype=torch.int64, device=labels.device)
+        row_labels = torch.empty(B * T, dtype=torch.int64, device=labels.device)
+        meta = torch.empty(2, dtype=torch.int32, device=labels.device)
+        check(load_lib().sd_loss_rows(lab.data_ptr(), _p(keep[-1] if speech_mask is not None else None),
+                                      _p(keep[1] if masks else None), _p(keep[2] if len(masks) > 1 else None),
+                                      rows.data_ptr(), row_labels.data_ptr(), meta.data_ptr(), B, T, _stream()), "sd_loss_rows")
+        n_rows, bad = meta.tolist()
+        if bad:
+            raise ValueError("attention_mask is not right-padded (a 1 follows a 0): the HIP attention kernels take a "
+                             "valid-prefix length per sequence, as ProcessedDataCollator produces (data.py:280-327)")
+        return rows[:n_rows], row_labels[:n_rows]
     nxt = torch.full_like(labels, -100)
     nxt[:, :-1] = labels[:, 1:]
     valid = nxt != -100
@@ -399,7 +417,6 @@ def loss_rows(labels, speech_mask=None, right_padded=()):
         m[:, :-1] = speech_mask.to(labels.device)[:, 1:] != 0
         valid &= m
     flat = valid.reshape(-1)
-    masks = [m for m in right_padded if m is not None]
     if labels.is_cuda:
         host = torch.stack([flat.sum()] + [left_padded(m.to(labels.device)).to(torch.int64) for m in masks]).tolist()
         if any(host[1:]):

@@ -7,8 +7,9 @@ the squared norm of the whole flat gradient and one ``sd_adamw_bf16`` launch upd
 (fp32 arithmetic in registers, one rounding of p / m / v to bf16), with the clip coefficient read from device
 memory -- no host synchronisation, ~8.5 GB of HBM traffic per step.
 
-Use with the HF Trainer:  ``DistillationTrainer(..., optimizers=(FlatAdamW(student, lr=...), None))`` and
-``max_grad_norm=0`` in TrainingArguments when ``clip`` is given here (otherwise HF clips tensor by tensor).
+``DistillationTrainer.create_optimizer`` builds it in place of HF's default AdamW, and its ``_clip_grad_norm`` hook calls
+``grad_norm(max_grad_norm)`` so that HF's clipping (one ``clip_grad_norm_`` over ~310 tensors, 10 ms of host time)
+becomes one reduction plus a coefficient applied inside the update.  Stand-alone: ``FlatAdamW(student, clip=1.0)``.
 Weight decay applies to matrices only (norm gains are excluded, as HF's parameter grouping does).
 """
 import torch
@@ -25,6 +26,7 @@ class FlatAdamW(torch.optim.Optimizer):
         self.exp_avg_sq = torch.zeros_like(model.flat)
         self._sumsq = torch.zeros(1, dtype=torch.float32, device=model.flat.device)
         self._step = 0
+        self._measured_clip = None  # set by grad_norm() for the following step()
         # contiguous runs of matrices / gains in the flat layout (for decay on matrices only)
         runs, cur = [], None
         for name, (o, n, shape) in model._slices.items():
@@ -46,7 +48,9 @@ class FlatAdamW(torch.optim.Optimizer):
         self._step += 1
         clip = float(g["clip"])
         ss = None
-        if clip > 0:
+        if self._measured_clip is not None:   # grad_norm() already reduced THIS gradient: the kernel clips against it
+            clip, ss, self._measured_clip = self._measured_clip, self._sumsq, None
+        elif clip > 0:
             self._sumsq.zero_()
             ops.sumsq(m.flat_grad, self._sumsq)
             ss = self._sumsq
@@ -57,6 +61,17 @@ class FlatAdamW(torch.optim.Optimizer):
             ops.adamw_(m.flat[a:b], m.flat_grad[a:b], self.exp_avg[a:b], self.exp_avg_sq[a:b], float(g["lr"]), b1, b2,
                        g["eps"], wd if is_mat else 0.0, self._step, ss, clip)
         return None
+
+    @torch.no_grad()
+    def grad_norm(self, max_norm):
+        """L2 norm of the whole gradient (a 0-d fp32 tensor, no host sync) = what ``clip_grad_norm_`` returns (HF
+        trainer.py:2535-2539); the next ``step()`` applies min(1, max_norm / (norm + 1e-6)) to the gradient INSIDE the
+        fused update instead of rewriting the 1.2 GB gradient buffer first (``.grad`` itself stays unclipped).
+        max_norm = inf (HF asks that way for the norm alone) or <= 0: measure only."""
+        self._sumsq.zero_()
+        ops.sumsq(self.model.flat_grad, self._sumsq)
+        self._measured_clip = float(max_norm) if 0 < max_norm < float("inf") else 0.0
+        return self._sumsq.sqrt().squeeze(0)
 
     def state_dict(self):
         """HF Trainer checkpoints ``optimizer.state_dict()`` (optimizer.pt): the flat bf16 moments + step count."""
@@ -73,6 +88,6 @@ class FlatAdamW(torch.optim.Optimizer):
             self.exp_avg_sq.copy_(flat["exp_avg_sq"])
             self._step = int(flat["step"])
 
-    def grad_norm(self):
-        """Global gradient norm seen by the last step (device tensor)."""
+    def last_grad_norm(self):
+        """Global gradient norm seen by the last step / measurement (device tensor)."""
         return self._sumsq.sqrt()

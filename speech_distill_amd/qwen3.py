@@ -360,6 +360,12 @@ class HipQwen3ForCausalLM(nn.Module):
         return m
 
     # ------------------------------------------------------------------ HF/Trainer protocol no-ops
+    def train(self, mode: bool = True):
+        """``nn.Module.train`` walks every submodule; the ~400 HF-named ones here only hold parameter views, and HF's
+        ``training_step`` calls ``model.train()`` on every micro-step (1.4 ms of host time with the GPU idle)."""
+        self.training = mode
+        return self
+
     def gradient_checkpointing_enable(self, gradient_checkpointing_kwargs=None, **_):
         """train.py:204-208 / TrainingArguments(gradient_checkpointing=True) (train.py:340), on by default in the reference.
 

@@ -40,6 +40,9 @@ class DistillationTrainer(Trainer):
         # per step for the row count.  Off: the full [B,T,V] path; return_outputs=True always uses the full path.
         self.compact_head = True
         self._hip_dp = None
+        # The optimizer HF would build by default (AdamW over ~310 HF-named tensors, HF trainer.py:1778-1796) is replaced
+        # by the one-launch FlatAdamW over the flat buffers when the student offers them; set False to keep HF's.
+        self.fused_optimizer = True
 
     # ------------------------------------------------------------------------------ HF Trainer plumbing
     def _wrap_model(self, model, training=True, dataloader=None):
@@ -56,6 +59,39 @@ class DistillationTrainer(Trainer):
                 self._hip_dp = ddp.HipDataParallel(model)
             return self._hip_dp
         return super()._wrap_model(model, training=training, dataloader=dataloader)
+
+    def create_optimizer(self):
+        """HF trainer.py `create_optimizer`: TrainingArguments' default is torch AdamW (the reference passes no
+        ``optim``, train.py:331-354).  For a flat-buffer student on the GPU the same update -- same hyper-parameters,
+        weight decay on matrices only like HF's parameter groups, moments in the parameters' dtype (quirk Q5) -- is ONE
+        fused launch over the flat parameter / gradient / moment buffers (``sd_adamw_bf16``).  HF keeps clipping
+        (``max_grad_norm``) and the learning-rate schedule: the scheduler writes ``param_groups[0]["lr"]``."""
+        core = ddp.unwrap(self.model)
+        default_adamw = str(getattr(self.args.optim, "value", self.args.optim)).startswith("adamw_torch")
+        if (self.optimizer is None and self.fused_optimizer and default_adamw and isinstance(core, HipQwen3ForCausalLM)
+                and core.flat.is_cuda and all(p.requires_grad for p in core.parameters())):
+            from .optim import FlatAdamW
+            self.optimizer = FlatAdamW(core, lr=self.args.learning_rate, betas=(self.args.adam_beta1, self.args.adam_beta2),
+                                       eps=self.args.adam_epsilon, weight_decay=self.args.weight_decay)
+            return self.optimizer
+        return super().create_optimizer()
+
+    def _clip_grad_norm(self, model):
+        """HF trainer.py:2535-2539 calls ``clip_grad_norm_`` over ~310 parameter tensors (10 ms of host time per
+        optimizer step with the GPU idle).  With the flat buffers the norm is one reduction, and FlatAdamW folds the
+        clip coefficient into its update; the returned pre-clip norm is the same number HF logs as ``grad_norm``."""
+        core = ddp.unwrap(model)
+        opt = getattr(self.optimizer, "optimizer", self.optimizer)
+        if isinstance(core, HipQwen3ForCausalLM) and core.flat_grad is not None and core.flat_grad.is_cuda:
+            from .optim import FlatAdamW
+            if isinstance(opt, FlatAdamW) and opt.model is core:
+                return opt.grad_norm(self.args.max_grad_norm)
+            ss = torch.zeros(1, dtype=torch.float32, device=core.flat_grad.device)
+            ops.sumsq(core.flat_grad, ss)
+            norm = ss.sqrt().squeeze(0)
+            core.flat_grad.mul_((self.args.max_grad_norm / (norm + 1e-6)).clamp(max=1.0).to(core.flat_grad.dtype))
+            return norm
+        return super()._clip_grad_norm(model)
 
     def _save(self, output_dir=None, state_dict=None):
         """HF trainer.py `_save`: a model that is not a PreTrainedModel gets a bare ``model.safetensors``.  The

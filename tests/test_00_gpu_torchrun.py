@@ -74,6 +74,7 @@ def test_two_rank_train_script_equals_one_rank_on_the_concatenated_batch():
     # = 8 micro-batches = 4 optimizer steps per rank, communication only on the 4 last micro-batches
     for r in (r0, r1):
         assert r["wrapped"] == "HipDataParallel" and r["world_size"] == 2 and r["global_step"] == 4
+        assert r["optimizer"] == "FlatAdamW"  # DistillationTrainer.create_optimizer: one fused launch, not 310 tensors
         assert r["reducer"] == {"backwards": 8, "synced": 4}
     assert one["wrapped"] == "HipDataParallel" and one["reducer"] is None and one["global_step"] == 4
     # both ranks: the same logged losses (HF gathers and averages them) and bitwise-identical parameters at the end

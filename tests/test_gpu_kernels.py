@@ -611,3 +611,52 @@ def test_adamw_and_clip(ops):
     check_close("adamw_p", pd, P, 8e-3, 3e-3)
     check_close("adamw_m", md, Mo, 8e-3, 3e-3)
     check_close("adamw_v", vd, Vo, 8e-3, 3e-3)
+
+
+# ------------------------------------------------------------------------------------------ loss rows
+@pytest.mark.parametrize("B,T", [(1, 7), (4, 512), (3, 341), (5, 1000), (2, 2048)])
+def test_loss_rows_kernel_equals_the_reference_rule(ops, B, T):
+    """sd_loss_rows (one launch) == the shift / -100 / speech-mask rule of distillation_loss.py:31-45, which the CPU
+    branch of ops.loss_rows states with plain torch ops: same rows in the same order, same predicted labels; bit-exact
+    (index work).  Also: no valid row, every row valid, and the right-padding check of both attention masks."""
+    g = torch.Generator().manual_seed(B * T)
+    labels = torch.randint(0, 1000, (B, T), generator=g)
+    labels[torch.rand(B, T, generator=g) < 0.4] = -100
+    speech = (torch.rand(B, T, generator=g) < 0.7).long()
+    lens = torch.randint(1, T + 1, (B,), generator=g)
+    am = (torch.arange(T)[None, :] < lens[:, None]).long()
+    for sm in (None, speech):
+        want_r, want_l = ops.loss_rows(labels, sm, right_padded=(am, am))          # CPU branch: the rule itself
+        got_r, got_l = ops.loss_rows(to_dev(labels), None if sm is None else to_dev(sm), right_padded=(to_dev(am), None))
+        assert torch.equal(got_r.cpu(), want_r) and torch.equal(got_l.cpu(), want_l), (B, T, sm is None)
+    none_r, none_l = ops.loss_rows(to_dev(torch.full((B, T), -100)))
+    assert none_r.numel() == 0 and none_l.numel() == 0
+    all_r, all_l = ops.loss_rows(to_dev(torch.ones(B, T, dtype=torch.long)))
+    assert all_r.numel() == B * (T - 1)
+    if T > 2:
+        bad = am.clone()
+        bad[B - 1] = 1
+        bad[B - 1, 0] = 0  # left padding in the last sequence
+        with pytest.raises(ValueError, match="right-padded"):
+            ops.loss_rows(to_dev(labels), None, right_padded=(to_dev(am), to_dev(bad)))
+        # a float / bool mask is accepted too
+        ops.loss_rows(to_dev(labels), to_dev(speech).bool(), right_padded=(to_dev(am).float(),))
+
+
+def test_gradient_norm_reduction_is_bitwise_reproducible(ops):
+    """sd_sumsq_bf16 feeds the clip coefficient of the fused AdamW: data-parallel ranks hold identical gradients and must
+    compute the identical norm, so the reduction has a fixed order (no atomics).  Same buffer, 20 launches, one value;
+    and the value is right (fp64 reference)."""
+    g = torch.Generator().manual_seed(5)
+    x = to_dev(bf(torch.randn(7_340_033, generator=g)))  # not a multiple of 8: tail path too
+    outs = []
+    for _ in range(20):
+        out = torch.zeros(1, dtype=torch.float32, device=x.device)
+        ops.sumsq(x, out)
+        outs.append(float(out))
+    assert len(set(outs)) == 1, sorted(set(outs))
+    ref = float(x.double().pow(2).sum())
+    assert abs(outs[0] - ref) <= 1e-5 * ref
+    acc = torch.full((1,), 3.0, dtype=torch.float32, device=x.device)  # accumulates into `out`
+    ops.sumsq(x, acc)
+    assert abs(float(acc) - 3.0 - outs[0]) <= 1e-6 * outs[0]

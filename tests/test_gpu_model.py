@@ -502,6 +502,32 @@ def test_extract_script_end_to_end_on_disk(sda, tmp_path, monkeypatch):
         assert all(len(set(row.tolist())) == 16 for row in i), r    # no index twice
 
 
+def test_trainer_clip_hook_equals_clip_grad_norm(sda):
+    """DistillationTrainer._clip_grad_norm -> FlatAdamW.grad_norm: the value HF logs as grad_norm equals
+    torch.nn.utils.clip_grad_norm_'s return over the HF-named parameters (HF trainer.py:2535-2539), the gradient buffer
+    is left untouched, and the following step() equals the step of an optimizer built with clip= folded in."""
+    from speech_distill_amd.optim import FlatAdamW
+    ids = torch.randint(0, 520, (2, 33), device=dev())
+    probe = torch.randn(2, 33, 520, device=dev())
+    outs = []
+    for mode in ("hook", "folded"):
+        model = sda.HipQwen3ForCausalLM(sda.Qwen3Dims(520, 128, 256, 2, 2, 1), device=dev(), seed=9)
+        opt = FlatAdamW(model, lr=1e-2, clip=0.5 if mode == "folded" else 0.0)
+        (model(input_ids=ids).logits.float() * probe).sum().backward()
+        if mode == "hook":
+            before = model.flat_grad.clone()
+            holders = [torch.nn.Parameter(torch.zeros_like(p, dtype=torch.float32)) for p in model.parameters()]
+            for hp, p in zip(holders, model.parameters()):
+                hp.grad = p.grad.detach().float().clone()
+            ref = torch.nn.utils.clip_grad_norm_(holders, float("inf"))
+            got = opt.grad_norm(0.5)
+            assert got.dim() == 0 and abs(float(got) - float(ref)) <= 2e-3 * float(ref), (float(got), float(ref))
+            assert float(ref) > 0.5 and torch.equal(before, model.flat_grad)
+        opt.step()
+        outs.append(model.flat.clone())
+    assert torch.equal(outs[0], outs[1])
+
+
 def test_flat_adamw_matches_torch_adamw(sda):
     """FlatAdamW (one fused launch, bf16 moments, clip folded in) vs torch.optim.AdamW on fp32 copies + clip_grad_norm_."""
     from speech_distill_amd.optim import FlatAdamW
