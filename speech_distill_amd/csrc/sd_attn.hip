@@ -225,7 +225,10 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const bf16* __restrict__ 
   ATT_STAMP();  // 0: kernel entry
   const int grp = w8 >> 2, rb = w8 & 1, half = (w8 >> 1) & 1;
   const int w = grp * 2 + rb;  // 0..3 inside my half: staging share and merge slot
-  const int tA = n64 - 1 - wg.pair, tB = wg.pair;  // heavy / light 64-row query tile of this workgroup
+  // heavy / light 64-row query tile of this workgroup.  (Pairing ADJACENT tiles instead, which keeps both tiles' waves
+  // busy for the whole stream, was measured for launches of several rounds of workgroups: slower at every shape, e.g.
+  // B=16,T=512 62.5 vs 55.6 us, B=4,T=2048 134.5 vs 131.5 us -- two working waves per SIMD share one vector ALU.)
+  const int tA = n64 - 1 - wg.pair, tB = wg.pair;
   const bool active = grp == 0 || tB != tA;      // odd tile count: the middle tile has no partner
   const int hkv = wg.hkv, b = wg.b;
   const int hq = hkv * (Hq / Hkv) + wg.member_head;
@@ -267,44 +270,68 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const bf16* __restrict__ 
 
   auto visible = [&](int i) { const int kv0 = i * 64 + 32 * half; return active && kv0 < kv_hi && kv0 <= q0w + 31; };
   // One tile = S^T (8 MFMAs, K fragments from LDS) -> online softmax (VALU) -> O^T += V^T P^T (8 MFMAs, transposed V
-  // reads, requested before the softmax so that they are there when it ends).  Measured with the stamp build
-  // (tests/bench_attn_stamps.py): ~1 750 cycles per tile for 512 cycles of MFMA -- the heavy tile's wave is alone on its
-  // SIMD once the light tile's wave has retired, so nothing overlaps its dependent chain.
-  auto tile = [&](int i, const char* ks, const char* vs) {
+  // reads, requested before the softmax so that they are there when it ends).  The loop is VALU-bound, not latency- or
+  // MFMA-bound (ISA count in round 2: 350 vector-ALU instructions per tile = ~1 600 issue cycles beside 512 cycles of
+  // MFMA; two working waves per SIMD take twice as long), so everything that does not depend on the tile is computed
+  // once: the per-lane LDS offsets of the K fragments and of the transposed V reads (a tile is then one add per read),
+  // and the causal / padding mask sits behind a scalar branch that only the diagonal tiles take.
+  unsigned kfo[8], vfo[2][8];
+#pragma unroll
+  for (int st = 0; st < 8; ++st) {
+    const int row = 32 * half + (lane & 31), ch = 2 * st + (lane >> 5);
+    kfo[st] = (unsigned)(row * 256 + ((ch ^ f_swz(row)) << 4));
+  }
+  {
+    const int gi = lane >> 4, i16 = lane & 15, q4 = i16 >> 2, pp = i16 & 3;
+    const int chl = (gi & 1) * 2 + (pp >> 1);
+#pragma unroll
+    for (int ss = 0; ss < 2; ++ss) {
+      const int rA = 32 * half + 16 * ss + 4 * (gi >> 1) + q4, rB = rA + 8;
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        const int ch = db * 4 + chl;
+        vfo[ss][2 * db] = (unsigned)(8 * (pp & 1) + rA * 256 + ((ch ^ f_swz(rA)) << 4));
+        vfo[ss][2 * db + 1] = (unsigned)(8 * (pp & 1) + rB * 256 + ((ch ^ f_swz(rB)) << 4));
+      }
+    }
+  }
+  const unsigned smem_a = lds_addr(smem);
+  auto tile = [&](int i, int stage) {
+    const char* ks = smem + stage * 2 * TILE;
+    const unsigned vsa = smem_a + stage * 2 * TILE + TILE;
     f32x16 s1;
 #pragma unroll
     for (int e = 0; e < 16; ++e) s1[e] = 0.f;
 #pragma unroll
-    for (int st = 0; st < 8; ++st) s1 = mfma32(row_frag(ks, 32 * half, st, lane), qf[st], s1);
+    for (int st = 0; st < 8; ++st) s1 = mfma32(*(const bf16x8*)(ks + kfo[st]), qf[st], s1);
     ATT_STAMP_AT(i == 3, 201);  // S^T MFMAs issued
     sd_u64 rv0[8], rv1[8];
-    tr_issue4(vs, 32 * half, lane, rv0);
-    tr_issue4(vs, 32 * half + 16, lane, rv1);
+#pragma unroll
+    for (int db = 0; db < 4; ++db) lds_tr16_pair_asm(rv0[2 * db], rv0[2 * db + 1], vsa + vfo[0][2 * db], vsa + vfo[0][2 * db + 1]);
+#pragma unroll
+    for (int db = 0; db < 4; ++db) lds_tr16_pair_asm(rv1[2 * db], rv1[2 * db + 1], vsa + vfo[1][2 * db], vsa + vfo[1][2 * db + 1]);
     const int kv0 = i * 64 + 32 * half;
-    const bool need_mask = (kv0 + 31 > q0w) || (kv0 + 31 >= klen);  // wave-uniform: my keys touch the diagonal / padding
-    float mx = NEG;
+    // wave-uniform: my keys touch the diagonal / the padding (readfirstlane: a scalar branch, not 16 selects per tile)
+    const bool need_mask = __builtin_amdgcn_readfirstlane((int)((kv0 + 31 > q0w) || (kv0 + 31 >= klen))) != 0;
     if (need_mask) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int key = kv0 + acc_row(e, h);
-        const float v = key > lim ? NEG : s1[e];
-        s1[e] = v;
-        mx = fmaxf(mx, v);
-      }
-    } else {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s1[e]);
+      for (int e = 0; e < 16; ++e) s1[e] = (kv0 + acc_row(e, h)) > lim ? NEG : s1[e];
     }
+    float mx = fmaxf(fmaxf(s1[0], s1[1]), s1[2]);
+#pragma unroll
+    for (int e = 3; e < 15; e += 2) mx = fmaxf(fmaxf(mx, s1[e]), s1[e + 1]);
+    mx = fmaxf(mx, s1[15]);
     ATT_STAMP_AT(i == 3, 202);  // lane maxima (S^T complete)
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     ATT_STAMP_AT(i == 3, 203);  // row maxima
     const float mn = fmaxf(m, mx);
     const float alpha = __builtin_amdgcn_exp2f((m - mn) * c);
     m = mn;
+    const float mnc = -mn * c;
     float rs = 0.f;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      const float p = __builtin_amdgcn_exp2f((s1[e] - mn) * c);
+      const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[e], c, mnc));
       s1[e] = p;
       rs += p;
     }
@@ -346,7 +373,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const bf16* __restrict__ 
     ATT_STAMP();  // 4+4i: next tile issued
     if (visible(i)) {
       ATT_STAMP_AT(i == 3, 200);
-      tile(i, smem + (i & 3) * 2 * TILE, smem + (i & 3) * 2 * TILE + TILE);
+      tile(i, i & 3);
     }
     ATT_STAMP();  // 5+4i: tile computed (issue side)
   }

@@ -26,7 +26,7 @@ def timeit(fn, iters=50, warm=5):
 
 def main():
     Hq, Hkv = 16, 8
-    for B, T in ((32, 64), (16, 128), (8, 256), (4, 512), (2, 1024), (1, 2048), (8, 512), (16, 512)):
+    for B, T in ((32, 64), (16, 128), (8, 256), (4, 512), (2, 1024), (1, 2048), (8, 512), (16, 512), (4, 1024), (4, 2048)):
         M = B * T
         qkv = torch.randn(M, (Hq + 2 * Hkv) * 128, device=dev).bfloat16()
         q, k, v = qkv[:, :Hq * 128], qkv[:, Hq * 128:(Hq + Hkv) * 128], qkv[:, (Hq + Hkv) * 128:]
