@@ -735,6 +735,7 @@ __global__ __launch_bounds__(768) void gemm_pstag_kernel(const bf16* __restrict_
           A_PIECES / 2 + w * CW);
   int cf_tile = 0, cf_k = 0;
   unsigned cf_a = 0;
+  (void)cf_a;  // read in the device pass only
   auto cf_set = [&](int idx) {
     int tm = 0, tn = 0;
     if (idx < my_tiles) origin(idx, tm, tn);
@@ -935,6 +936,7 @@ __global__ __launch_bounds__(512) void gemm_p256_kernel(const bf16* __restrict__
 #endif
   int pf_tile = 0, pf_k = 0;
   unsigned pf_a = 0, pf_b = 0;
+  (void)pf_a; (void)pf_b;  // read in the device pass only
   auto pf_set = [&](int idx) {
     int tm = 0, tn = 0;
     if (idx < my_tiles) origin(idx, tm, tn);
