@@ -33,6 +33,24 @@ SD_DEV float wave_sum(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+// Cross-lane moves inside a 16-lane DPP row as VALU operands (v_*_dpp), instead of __shfl_xor, which hipcc lowers to
+// ds_bpermute_b32 -- an LDS round trip per call (128 of them sat in the q|k|v epilogue).  Bit-identical replacements.
+template <int CTRL>
+SD_DEV float dpp_move(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+// sum over the 16 lanes of a row, result in every lane: quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror,
+// row_mirror = the xor 1, 2, 4, 8 butterfly (after two steps all lanes of a quad agree, after three all of a half-row)
+SD_DEV float row16_sum(float v) {
+  v += dpp_move<0xB1>(v);
+  v += dpp_move<0x4E>(v);
+  v += dpp_move<0x141>(v);
+  v += dpp_move<0x140>(v);
+  return v;
+}
+// value of lane (i ^ 8) of the same row: row_ror:8
+SD_DEV float row16_xor8(float v) { return dpp_move<0x128>(v); }
+
 SD_DEV float wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

@@ -282,7 +282,7 @@ SD_DEV void write_out(const float* cs, bf16* C, const EpiPre<EPI, BM, NTHR>& pre
       float sdel = 0.f;
 #pragma unroll
       for (int e = 0; e < 8; ++e) sdel += (float)o[e] * (float)pre.a[it][e];
-      sdel += __shfl_xor(sdel, 1, 64); sdel += __shfl_xor(sdel, 2, 64); sdel += __shfl_xor(sdel, 4, 64); sdel += __shfl_xor(sdel, 8, 64);
+      sdel = row16_sum(sdel);
       if (oc == 0 && gm < M) {
         const int bb = gm / ea.T, t = gm - bb * ea.T;
         ((float*)ea.out2)[((long)bb * ea.Hq + tn) * ea.T + t] = sdel;
@@ -296,14 +296,14 @@ SD_DEV void write_out(const float* cs, bf16* C, const EpiPre<EPI, BM, NTHR>& pre
         float f[8], ss = 0.f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) { f[e] = (float)raw[e]; ss += f[e] * f[e]; }
-        ss += __shfl_xor(ss, 1, 64); ss += __shfl_xor(ss, 2, 64); ss += __shfl_xor(ss, 4, 64); ss += __shfl_xor(ss, 8, 64);
+        ss = row16_sum(ss);
         const float rs = rsqrtf(ss * (1.f / 128.f) + ea.eps);
         const bf16x8 gv = pre.gain, cv = pre.a[it], sv = pre.b[it];
         bf16x8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const float nrm = (float)(bf16)((float)gv[e] * (float)(bf16)(f[e] * rs));
-          const float pr = __shfl_xor(nrm, 8, 64);
+          const float pr = row16_xor8(nrm);
           const float rot = (oc < 8) ? -pr : pr;
           o[e] = (bf16)(nrm * (float)cv[e] + rot * (float)sv[e]);
         }
