@@ -237,7 +237,7 @@ __global__ __launch_bounds__(256) void qknorm_rope_fwd_kernel(const bf16* __rest
   float ss = 0.f;
 #pragma unroll
   for (int e = 0; e < 8; ++e) ss += f[e] * f[e];
-  ss += __shfl_xor(ss, 1, 64); ss += __shfl_xor(ss, 2, 64); ss += __shfl_xor(ss, 4, 64); ss += __shfl_xor(ss, 8, 64);
+  ss = row16_sum(ss);
   const float rs = rsqrtf(ss * (1.f / 128.f) + eps);
   unpack8(*(const bf16x8*)((hh < Hq ? qw : kw) + j * 8), g);
   unpack8(*(const bf16x8*)(cosb + (long)t * 128 + j * 8), cs);
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256) void qknorm_rope_fwd_kernel(const bf16* __rest
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     const float n = (float)(bf16)(g[e] * (float)(bf16)(f[e] * rs));  // normed value as HF holds it (bf16)
-    const float p = __shfl_xor(n, 8, 64);
+    const float p = row16_xor8(n);
     const float rot = (j < 8) ? -p : p;
     o[e] = n * cs[e] + rot * sn[e];
   }
@@ -301,18 +301,18 @@ __global__ __launch_bounds__(256) void qknorm_rope_bwd_kernel(const bf16* __rest
       float ss = 0.f;
 #pragma unroll
       for (int e = 0; e < 8; ++e) ss += f[e] * f[e];
-      ss += __shfl_xor(ss, 1, 64); ss += __shfl_xor(ss, 2, 64); ss += __shfl_xor(ss, 4, 64); ss += __shfl_xor(ss, 8, 64);
+      ss = row16_sum(ss);
       const float rs = rsqrtf(ss * (1.f / 128.f) + eps);
       // RoPE^T:  dn[i] = dy[i] cos[i] + (i<64 ?  dy[i+64] sin[i+64] : -dy[i-64] sin[i-64])
       float dn[8], dot = 0.f;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float z = dy[e] * sn[e];
-        const float pz = __shfl_xor(z, 8, 64);
+        const float pz = row16_xor8(z);
         dn[e] = dy[e] * cs[e] + ((j < 8) ? pz : -pz);
         dot += dn[e] * g[e] * f[e] * rs;
       }
-      dot += __shfl_xor(dot, 1, 64); dot += __shfl_xor(dot, 2, 64); dot += __shfl_xor(dot, 4, 64); dot += __shfl_xor(dot, 8, 64);
+      dot = row16_sum(dot);
       dot *= (1.f / 128.f);
       float o[8];
 #pragma unroll
