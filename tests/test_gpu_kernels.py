@@ -443,6 +443,28 @@ def test_embedding_fwd_bwd(ops):
     check_close("embedding_bwd", dE, ref, 8e-3, 2e-3)
 
 
+def test_embedding_bwd_many_duplicates_fixed_order(ops):
+    """5 000 tokens over 300 ids (every id ~16 times, duplicates across the 32-token words of the kernel's bitmap): the
+    gradient row of an id is base + the fp32 sum of its token rows taken in increasing token order -- bit for bit, and
+    the same on every run (HF:381 embedding backward is an index_add with unspecified order)."""
+    g = torch.Generator().manual_seed(14)
+    V, H, M = 300, 1024, 5000
+    ids = torch.randint(0, V, (M,), generator=g)
+    dx = bf(torch.randn(M, H, generator=g))
+    dE0 = bf(torch.randn(V, H, generator=g))
+    got = ops.embedding_bwd(to_dev(ids), to_dev(dx), to_dev(dE0.clone())).cpu()
+    again = ops.embedding_bwd(to_dev(ids), to_dev(dx), to_dev(dE0.clone())).cpu()
+    assert torch.equal(got, again)
+    want = dE0.clone()
+    for v in range(V):
+        rows = (ids == v).nonzero().reshape(-1)
+        acc = torch.zeros(H, dtype=torch.float32)
+        for i in rows.tolist():  # increasing token order, fp32, one addition at a time
+            acc = acc + dx[i].float()
+        want[v] = (dE0[v].float() + 1.0 * acc).bfloat16()
+    assert torch.equal(got, want)
+
+
 # -------------------------------------------------------------------------------------- attention
 # the last three: B * Hkv is a multiple of 8, i.e. the XCD-aware workgroup numbering (attn_wg) instead of the natural one,
 # with G = 2 / 1 query heads per kv head, an odd number of tile pairs and a ragged last tile
