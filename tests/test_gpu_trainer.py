@@ -293,3 +293,47 @@ def test_extract_then_train_from_precomputed_topk_on_disk(sda, tmp_path, monkeyp
         assert abs(a["distill_loss"] - b["distill_loss"]) <= 2e-3 * abs(a["distill_loss"]), (a, b)
         assert abs(a["student_loss"] - b["student_loss"]) <= 2e-3 * abs(a["student_loss"]), (a, b)
         assert abs(a["teacher_loss"] - b["teacher_loss"]) <= 2e-3 * max(1.0, abs(a["teacher_loss"])), (a, b)
+
+
+def test_hf_default_optimizer_still_works_and_agrees_with_the_fused_one(sda):
+    """DistillationTrainer builds FlatAdamW and folds HF's clipping into it by default; with ``fused_optimizer = False`` it
+    keeps HF's own AdamW (torch, ~310 parameter views) and clips the flat gradient buffer in place.  Same data, same
+    init: the logged gradient norms agree (same reduction) and the loss trajectories stay together."""
+    from transformers import TrainingArguments
+    from speech_distill_amd.collator import ProcessedDataCollator
+    from speech_distill_amd.optim import FlatAdamW
+    from speech_distill_amd.trainer import DistillationTrainer
+    z, st, te, sw, tw, feats, pad, bos = _c1(sda)
+
+    class DS(torch.utils.data.Dataset):
+        def __len__(self):
+            return len(feats)
+
+        def __getitem__(self, i):
+            return dict(feats[i])
+
+    def run(fused):
+        student, teacher = _build(sda, st, sw), _build(sda, te, tw)
+        teacher.eval().requires_grad_(False)
+        args = TrainingArguments(
+            output_dir=tempfile.mkdtemp(), per_device_train_batch_size=4, gradient_accumulation_steps=2, max_steps=3,
+            learning_rate=1e-3, logging_steps=1, save_strategy="no", report_to=[], remove_unused_columns=False,
+            label_names=["labels"], seed=42, data_seed=42, lr_scheduler_type="constant", warmup_steps=0, weight_decay=0.0,
+            max_grad_norm=0.5, dataloader_num_workers=0, bf16=True)
+        tr = DistillationTrainer(model=student, args=args, train_dataset=DS(), teacher_model=teacher, temperature=2.0,
+                                 alpha=0.5, top_k=16, data_collator=ProcessedDataCollator(_Tok(pad, bos), pad_token_id=pad))
+        tr.fused_optimizer = fused
+        tr._get_train_sampler = lambda *a, **k: torch.utils.data.SequentialSampler(tr.train_dataset)
+        tr.train()
+        opt = getattr(tr.optimizer, "optimizer", tr.optimizer)
+        logs = [h for h in tr.state.log_history if "loss" in h]
+        return opt, [h["loss"] for h in logs], [h["grad_norm"] for h in logs]
+
+    opt_f, loss_f, gn_f = run(True)
+    opt_h, loss_h, gn_h = run(False)
+    assert isinstance(opt_f, FlatAdamW) and not isinstance(opt_h, FlatAdamW) and isinstance(opt_h, torch.optim.AdamW)
+    record("fused_vs_hf_optimizer", loss_fused=loss_f, loss_hf=loss_h, gn_fused=gn_f, gn_hf=gn_h)
+    assert len(loss_f) == len(loss_h) == 3
+    assert abs(gn_f[0] - gn_h[0]) <= 1e-3 * gn_h[0]           # step 1: identical gradients, two routes to the same norm
+    np.testing.assert_allclose(loss_f, loss_h, rtol=2e-2)     # bf16 moments either way; the updates differ by rounding
+    np.testing.assert_allclose(gn_f, gn_h, rtol=5e-2)
