@@ -15,10 +15,7 @@
  *     concurrent backward calls never share an event); (2) the sd_prof_* accumulators (only between
  *     sd_prof_begin/end); (3) measurement switches meant for tests and benchmarks, not for production use:
  *     sd_gemm_force_variant() and the environment variables SD_OVERLAP_MASK, SD_FUSE_STUDENT_SWIGLU, SD_GEMM_NO_P256,
- *     SD_GEMM_P256_MIN_TILES, SD_GEMM_NO_PERSIST, SD_GEMM_GROUP_M, SD_TOPK_NT (A/B switches, each read once); (4) one
- *     2048-float device buffer per GPU holding the per-workgroup partial sums of sd_sumsq_bf16 between its two launches
- *     (fixed-order reduction: the gradient norm is bit-identical on every data-parallel rank); calls to sd_sumsq_bf16
- *     on different streams of ONE device must not overlap;
+ *     SD_GEMM_P256_MIN_TILES, SD_GEMM_NO_PERSIST, SD_GEMM_GROUP_M, SD_TOPK_NT (A/B switches, each read once);
  *   - return value: SD_OK (0), a negative SD_ERR_* code, or a positive hipError_t from the launch.
  */
 #pragma once
@@ -206,7 +203,11 @@ int sd_kdloss_bwd_rows(const void* student_logits, const void* teacher_logits, c
 
 /* ---- fused AdamW on bf16 params with bf16 state (HF Trainer default optimizer on the bf16 student,
  * train.py:174,331-354; quirk Q5) and the global grad-norm / clip (HF trainer max_grad_norm). */
-int sd_sumsq_bf16(const void* x, int64_t n, float* out_accum, void* stream);
+/* out_accum[0] += sum x^2; `partials`: SD_SUMSQ_PARTIALS floats of caller-owned device scratch holding the per-workgroup
+ * sums between the two launches (fixed-order reduction: the norm is bit-identical on every data-parallel rank; calls
+ * that may overlap on different streams pass different scratch). */
+#define SD_SUMSQ_PARTIALS 2048
+int sd_sumsq_bf16(const void* x, int64_t n, float* out_accum, float* partials, void* stream);
 int sd_adamw_bf16(void* param, const void* grad, void* exp_avg, void* exp_avg_sq, int64_t n, float lr, float beta1,
                   float beta2, float eps, float weight_decay, int step, const float* grad_sumsq, float max_grad_norm,
                   void* stream);

@@ -49,6 +49,8 @@ class Params(C.Structure):
                 ("layers_host", C.POINTER(Layer))]
 
 
+SUMSQ_PARTIALS = 2048  # include/sd_hip.h SD_SUMSQ_PARTIALS
+
 KINDS = ["gemm_nt", "gemm_nn", "gemm_tn", "attn_fwd", "attn_bwd_dkv", "attn_bwd_dq", "loss_fwd", "loss_bwd", "topk",
          "rmsnorm", "qknorm_rope", "swiglu", "embedding", "optim", "misc", "gemm_nt_stag"]
 
@@ -96,7 +98,7 @@ PROTOTYPES = {
     "sd_rmsnorm_bwd_partial_rows": (_i, [_i, _i]),
     "sd_qknorm_rope_bwd_partial_rows": (_i, [_i, _i, _i]),
     "sd_colsum_reduce_batch": (_i, [_vp, _i, _vp]),
-    "sd_sumsq_bf16": (_i, [_vp, _i64, _vp, _vp]),
+    "sd_sumsq_bf16": (_i, [_vp, _i64, _vp, _vp, _vp]),
     "sd_adamw_bf16": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _vp, _f, _vp]),
     "sd_streams_overlap": (_i, [_vp, _vp, _f, C.POINTER(C.c_int)]),
     "sd_prof_begin": (_i, []),

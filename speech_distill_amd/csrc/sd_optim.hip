@@ -10,20 +10,19 @@ namespace {
 
 // Per-workgroup partial sums of sd_sumsq_bf16, combined by a second launch in a fixed order: the norm must come out
 // bit-identical on every data-parallel rank (it scales the update, and ranks that round it differently drift apart --
-// seen as different parameter checksums on two ranks when the partials were combined with atomicAdd).  One buffer per
-// device (the code object is loaded per device); two sd_sumsq_bf16 calls in flight on different streams of one device
-// would share it -- the optimizer step has no such concurrency.
-__device__ float g_sumsq_partials[2048];
+// seen as different parameter checksums on two ranks when the partials were combined with atomicAdd).  The partials
+// live in the CALLER's workspace (SD_SUMSQ_PARTIALS floats), so calls on different streams never share state.
+constexpr int kSumsqPartials = SD_SUMSQ_PARTIALS;
 
-__global__ __launch_bounds__(256) void sumsq_final_kernel(int nb, float* out) {
+__global__ __launch_bounds__(256) void sumsq_final_kernel(const float* __restrict__ partials, int nb, float* out) {
   __shared__ float sc[32];
   float s = 0.f;
-  for (int i = threadIdx.x; i < nb; i += 256) s += g_sumsq_partials[i];
+  for (int i = threadIdx.x; i < nb; i += 256) s += partials[i];
   s = block_sum<256>(s, sc);
   if (threadIdx.x == 0) out[0] += s;
 }
 
-__global__ __launch_bounds__(256) void sumsq_kernel(const bf16* __restrict__ x, long n8, long n, float* out) {
+__global__ __launch_bounds__(256) void sumsq_kernel(const bf16* __restrict__ x, long n8, long n, float* partials) {
   __shared__ float sc[32];
   float s = 0.f;
   for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < n8; q += (long)gridDim.x * 256) {
@@ -34,7 +33,7 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const bf16* __restrict__ x, 
   if (blockIdx.x == 0)
     for (long i = n8 * 8 + threadIdx.x; i < n; i += 256) { const float f = (float)x[i]; s += f * f; }
   s = block_sum<256>(s, sc);
-  if (threadIdx.x == 0) g_sumsq_partials[blockIdx.x] = s;
+  if (threadIdx.x == 0) partials[blockIdx.x] = s;
 }
 
 SD_DEV void adam1(float& p, float g, float& m, float& v, float lr, float b1, float b2, float eps, float wd, float bc1,
@@ -75,15 +74,17 @@ __global__ __launch_bounds__(256) void adamw_kernel(bf16* p, const bf16* __restr
 
 }  // namespace
 
-extern "C" int sd_sumsq_bf16(const void* x, int64_t n, float* out_accum, void* stream) {
+extern "C" int sd_sumsq_bf16(const void* x, int64_t n, float* out_accum, float* partials, void* stream) {
   if (n <= 0) return SD_ERR_SHAPE;
-  if ((uintptr_t)x & 15) return SD_ERR_ALIGN;
+  if (!partials) return SD_ERR_WORKSPACE;
+  if (((uintptr_t)x & 15) || ((uintptr_t)partials & 3)) return SD_ERR_ALIGN;
   const long n8 = n / 8;
-  const int nb = (int)((n8 + 255) / 256 < 2048 ? (n8 + 255) / 256 : 2048);
+  const int nb = (int)((n8 + 255) / 256 < kSumsqPartials ? (n8 + 255) / 256 : kSumsqPartials);
   const int grid = nb < 1 ? 1 : nb;
-  hipLaunchKernelGGL(sumsq_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, n8, (long)n, out_accum);
+  hipLaunchKernelGGL(sumsq_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, n8, (long)n, partials);
   SD_CHECK_LAUNCH();
-  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, grid, out_accum);
+  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)partials, grid,
+                     out_accum);
   SD_CHECK_LAUNCH();
   return 0;
 }

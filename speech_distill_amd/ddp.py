@@ -9,9 +9,14 @@ that the kernels producing it are enqueued (``sd_stage_cb``), so it runs under t
 backward kernels.  ``torch.distributed`` backend "nccl" is RCCL over xGMI on ROCm; "gloo" is used
 by the CPU tests of the bucketing logic.  The frozen teacher is replicated and never communicated.
 
-xGMI is point-to-point (7 links per GPU): per-layer buckets (31.5 MB for the 0.6B student) are
-large enough for RCCL to spread over all links; fusing more layers per bucket is a knob
-(``layers_per_bucket``).
+xGMI is point-to-point (7 links x ~153 GB/s per GPU, no switch): a RING all-reduce of a bucket of S bytes moves
+2*(W-1)/W*S per GPU over ONE link per direction, a DIRECT reduce-scatter + all-gather moves (W-1)/W*S/(W-1) = S/W per
+link over all W-1 links at once (13.8 ms vs ~2 ms for the 1.21 GB of student gradients at W = 8).
+Which of the two RCCL picks for ``all_reduce`` is its own choice, so both collective forms are offered -- ``algo=
+"allreduce"`` (one ``all_reduce(AVG)`` per bucket) and ``algo="rs_ag"`` (in-place ``reduce_scatter_tensor(AVG)`` +
+``all_gather_into_tensor`` on the same slice) -- together with the bucket size (``layers_per_bucket``: 31.5 MB per layer
+for the 0.6B student) and a per-bucket timing mode (``timing=True``: events on the communication stream + the exposed
+wait in ``finish``), so that a run on real links can tell them apart (``bench.py --comm-algo / --layers-per-bucket``).
 """
 from __future__ import annotations
 
@@ -49,13 +54,23 @@ def bucket_plan(layer_ranges, embed_range, norm_range, numel, layers_per_bucket=
 class FlatGradAllReduce:
     """Averages ``flat_grad`` over the process group, bucket by bucket, overlapped with backward."""
 
-    def __init__(self, flat_grad_getter, plan, group=None, comm_stream=None, split_embedding=False):
+    def __init__(self, flat_grad_getter, plan, group=None, comm_stream=None, split_embedding=False, algo="allreduce",
+                 timing=False, rehearse_single_rank=False):
+        if algo not in ("allreduce", "rs_ag"):
+            raise ValueError(f"algo {algo!r}: 'allreduce' or 'rs_ag'")
         self._get = flat_grad_getter
         self.plan = plan
         self.split_embedding = split_embedding
         self._emb = None
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # a one-rank process group issues every collective all the same (RCCL runs them as local copies): the
+        # rehearsal of the N > 1 call sequence on a one-GPU box (bench.py --force-dist, tests/test_00_gpu_rccl1.py)
+        self.active = self.world > 1 or (rehearse_single_rank and dist.is_initialized())
+        self.algo = algo
+        self.timing = timing
+        self._timed = []      # (stage, numel, start event, end event) of the current step
+        self._exposed = None  # (event before, event after) the main stream's wait for the communication stream
         self.sync = True
         backend = dist.get_backend(group) if dist.is_initialized() else "none"
         # RCCL ("nccl"): in-stream all_reduce(AVG) on a dedicated communication stream.  gloo (CPU tests,
@@ -81,11 +96,12 @@ class FlatGradAllReduce:
     def begin_step(self):
         self._works, self.issued = [], []
         self._emb = None
+        self._timed, self._exposed = [], None
         self.stats["backwards"] += 1
-        self.stats["synced"] += int(self.sync and self.world > 1)
+        self.stats["synced"] += int(self.sync and self.active)
 
     def wants_split_embedding(self):
-        return self.split_embedding and self.sync and self.world > 1
+        return self.split_embedding and self.sync and self.active
 
     def set_embedding_exchange(self, ids, dx0, embed_grad):
         """Called by the model before backward: token ids [M], buffer that will receive d loss / d embedding
@@ -127,7 +143,7 @@ class FlatGradAllReduce:
 
     def on_stage(self, stage):
         """Host callback from the backward runner: grads of `stage` are enqueued on the compute stream."""
-        if not self.sync or self.world == 1:
+        if not self.sync or not self.active:
             return
         if stage == STAGE_EMBED and self._emb is not None:
             if self.cuda:
@@ -135,7 +151,9 @@ class FlatGradAllReduce:
                 ev.record(torch.cuda.current_stream())
                 self.comm.wait_event(ev)
                 with torch.cuda.stream(self.comm):
+                    t0 = self._tick()
                     self._exchange_embedding_rows()
+                    self._tock(stage, self._emb[1].numel(), t0)
             else:
                 if self._emb[1].is_cuda:
                     torch.cuda.current_stream().synchronize()
@@ -156,7 +174,9 @@ class FlatGradAllReduce:
                 ev.record(torch.cuda.current_stream())
                 self.comm.wait_event(ev)
                 with torch.cuda.stream(self.comm):
-                    dist.all_reduce(chunk, op=dist.ReduceOp.AVG, group=self.group)
+                    t0 = self._tick()
+                    self._reduce_on_stream(chunk)
+                    self._tock(st, chunk.numel(), t0)
             else:  # gloo has no AVG: sum then scale (device tensors: wait for the producing kernels first)
                 if chunk.is_cuda:
                     torch.cuda.current_stream().synchronize()
@@ -164,22 +184,70 @@ class FlatGradAllReduce:
                 self._works.append((w, chunk))
             self.issued.append((st, a, b))
 
+    def _reduce_on_stream(self, chunk):
+        """Average one bucket over the group on the current (communication) stream, in place."""
+        W = self.world
+        if self.algo == "rs_ag" and chunk.numel() % W == 0:
+            # every tensor of the flat layout starts on a multiple of 8 elements, so buckets divide by W = 2, 4, 8.
+            # In place: rank r's shard of the sum lands in its own slot, then every rank gathers all slots.
+            n = chunk.numel() // W
+            r = dist.get_rank(self.group)
+            mine = chunk[r * n:(r + 1) * n]
+            dist.reduce_scatter_tensor(mine, chunk, op=dist.ReduceOp.AVG, group=self.group)
+            dist.all_gather_into_tensor(chunk, mine, group=self.group)
+        else:
+            dist.all_reduce(chunk, op=dist.ReduceOp.AVG, group=self.group)
+
+    def _tick(self):
+        if not self.timing:
+            return None
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def _tock(self, stage, numel, t0):
+        if t0 is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            self._timed.append((stage, numel, t0, e))
+
+    def timings(self):
+        """After a device synchronisation: ([(stage, bytes, ms on the communication stream)], exposed ms) of the last
+        step -- exposed = how long the compute stream sat in ``finish`` waiting for the communication stream."""
+        per = [(st, 2 * n, t0.elapsed_time(t1)) for st, n, t0, t1 in self._timed]
+        exposed = self._exposed[0].elapsed_time(self._exposed[1]) if self._exposed else None
+        return per, exposed
+
     def finish(self):
         """Order everything after the last all-reduce (stream wait on GPU, no host sync)."""
         if self.cuda and self.comm is not None:
-            torch.cuda.current_stream().wait_stream(self.comm)
+            if self.timing and self.sync and self.active:
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(torch.cuda.current_stream())
+                torch.cuda.current_stream().wait_stream(self.comm)
+                b.record(torch.cuda.current_stream())
+                self._exposed = (a, b)
+            else:
+                torch.cuda.current_stream().wait_stream(self.comm)
         for w, chunk in self._works:
             w.wait()
             chunk.div_(self.world)
         self._works = []
 
 
-def attach(model, group=None, layers_per_bucket=1, split_embedding=True):
-    """Wire the backward stage callback of a flat-gradient model (HipQwen3ForCausalLM) to overlapped all-reduces."""
+def attach(model, group=None, layers_per_bucket=None, split_embedding=True, algo=None, timing=False,
+           rehearse_single_rank=False):
+    """Wire the backward stage callback of a flat-gradient model (HipQwen3ForCausalLM) to overlapped all-reduces.
+    ``layers_per_bucket`` / ``algo`` default to the environment variables SD_LAYERS_PER_BUCKET (1) / SD_COMM_ALGO
+    ("allreduce"), so a ``torchrun scripts/train.py`` launch can A/B them without code changes."""
+    import os
+    layers_per_bucket = int(os.environ.get("SD_LAYERS_PER_BUCKET", "1")) if layers_per_bucket is None else layers_per_bucket
+    algo = os.environ.get("SD_COMM_ALGO", "allreduce") if algo is None else algo
     split_embedding = split_embedding and model.dims.tie_word_embeddings
     plan = bucket_plan(model.layer_ranges, model.embed_range, model.norm_range, model.numel_flat, layers_per_bucket,
                        split_embedding)
-    red = FlatGradAllReduce(lambda: model.flat_grad, plan, group, split_embedding=split_embedding)
+    red = FlatGradAllReduce(lambda: model.flat_grad, plan, group, split_embedding=split_embedding, algo=algo, timing=timing,
+                            rehearse_single_rank=rehearse_single_rank)
     model._stage_cb = red.on_stage
     model._reducer = red
     model.no_sync = red.no_sync
@@ -205,7 +273,7 @@ class HipDataParallel(torch.nn.Module):
     DDP does, gradient averaging by ``FlatGradAllReduce`` under the backward.  With one process it only forwards.
     """
 
-    def __init__(self, module, group=None, layers_per_bucket=1, split_embedding=True, broadcast_params=True):
+    def __init__(self, module, group=None, layers_per_bucket=None, split_embedding=True, broadcast_params=True):
         super().__init__()
         self.module = module
         self.reducer = None

@@ -392,11 +392,16 @@ def loss_rows(labels, speech_mask=None, right_padded=()):
     ValueError if one of them is not a valid-prefix mask (see HipQwen3ForCausalLM.forward)."""
     B, T = labels.shape
     masks = [m for m in right_padded if m is not None]
+    # every mask is indexed as [B, T] with the LABELS' B and T (the collator pads teacher and student separately,
+    # data.py:219-278: a teacher mask of another length is not this batch's grid)
+    for what, m in [("attention mask", m) for m in masks] + ([("speech_token_mask", speech_mask)] if speech_mask is not None else []):
+        if tuple(m.shape) != (B, T):
+            raise ValueError(f"loss_rows: {what} {tuple(m.shape)} != labels {(B, T)}")
     if labels.is_cuda and len(masks) <= 2:  # one launch (sd_loss_rows) + one 8-byte read
-        def i64(t):
+        def i64(t):  # masks: any dtype, non-zero = 1
             t = t.to(labels.device)
             return (t if t.dtype == torch.int64 else (t != 0).to(torch.int64)).contiguous()
-        lab = i64(labels)
+        lab = labels.to(torch.int64).contiguous()  # labels keep their VALUES (token ids, -100) whatever the int dtype
         keep = [lab] + [i64(m) for m in masks] + ([i64(speech_mask)] if speech_mask is not None else [])
         rows = torch.empty(B * T, dtype=torch.int64, device=labels.device)
         row_labels = torch.empty(B * T, dtype=torch.int64, device=labels.device)
@@ -456,8 +461,16 @@ def rows_scatter(src, rows, M):
 
 
 # --------------------------------------------------------------------------------------- optimizer
-def sumsq(x, out):
-    check(load_lib().sd_sumsq_bf16(x.data_ptr(), x.numel(), out.data_ptr(), _stream()), "sd_sumsq_bf16")
+def sumsq(x, out, partials=None):
+    """out[0] += sum(x^2) (deterministic two-launch reduction).  ``partials``: fp32 scratch of SUMSQ_PARTIALS elements the
+    caller owns (FlatAdamW keeps one); allocated per call when omitted, so concurrent calls never share state."""
+    from ._lib import SUMSQ_PARTIALS
+    if partials is None:
+        partials = torch.empty(SUMSQ_PARTIALS, dtype=torch.float32, device=x.device)
+    elif partials.dtype != torch.float32 or partials.numel() < SUMSQ_PARTIALS or not partials.is_cuda:
+        raise ValueError(f"partials: fp32 GPU scratch of at least {SUMSQ_PARTIALS} elements")
+    check(load_lib().sd_sumsq_bf16(x.data_ptr(), x.numel(), out.data_ptr(), partials.data_ptr(), _stream()),
+          "sd_sumsq_bf16")
 
 
 def adamw_(p, g, m, v, lr, beta1, beta2, eps, wd, step, grad_sumsq=None, max_norm=0.0):

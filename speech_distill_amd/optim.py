@@ -25,6 +25,7 @@ class FlatAdamW(torch.optim.Optimizer):
         self.exp_avg = torch.zeros_like(model.flat)
         self.exp_avg_sq = torch.zeros_like(model.flat)
         self._sumsq = torch.zeros(1, dtype=torch.float32, device=model.flat.device)
+        self._partials = torch.empty(2048, dtype=torch.float32, device=model.flat.device)  # sd_sumsq_bf16 scratch, this optimizer's own
         self._step = 0
         self._measured_clip = None  # set by grad_norm() for the following step()
         # contiguous runs of matrices / gains in the flat layout (for decay on matrices only)
@@ -52,7 +53,7 @@ class FlatAdamW(torch.optim.Optimizer):
             clip, ss, self._measured_clip = self._measured_clip, self._sumsq, None
         elif clip > 0:
             self._sumsq.zero_()
-            ops.sumsq(m.flat_grad, self._sumsq)
+            ops.sumsq(m.flat_grad, self._sumsq, self._partials)
             ss = self._sumsq
         b1, b2 = g["betas"]
         wd = float(g["weight_decay"])
@@ -69,7 +70,7 @@ class FlatAdamW(torch.optim.Optimizer):
         fused update instead of rewriting the 1.2 GB gradient buffer first (``.grad`` itself stays unclipped).
         max_norm = inf (HF asks that way for the norm alone) or <= 0: measure only."""
         self._sumsq.zero_()
-        ops.sumsq(self.model.flat_grad, self._sumsq)
+        ops.sumsq(self.model.flat_grad, self._sumsq, self._partials)
         self._measured_clip = float(max_norm) if 0 < max_norm < float("inf") else 0.0
         return self._sumsq.sqrt().squeeze(0)
 

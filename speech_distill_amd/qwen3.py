@@ -65,6 +65,21 @@ class Qwen3Dims:
     def teacher_17b(cls):  # soulxpodcast/config.py:12-42
         return cls(159488, 2048, 6144, 28, 16, 8)
 
+    def matmul_params(self):
+        """Parameters that take part in a matmul per token: the decoder's projections + the (tied) lm_head."""
+        h, I = self.hidden_size, self.intermediate_size
+        per_layer = h * (self.q_dim + 2 * self.kv_dim) + self.q_dim * h + 3 * h * I
+        return self.num_hidden_layers * per_layer + self.vocab_size * h
+
+    def flops_per_token(self, T):
+        """Algorithmic forward FLOPs per token: 2 per matmul parameter + causal attention
+        (half of 4*T*Hq*d per layer).  Backward = 2x this; a distillation micro-step = 3x student + 1x teacher."""
+        attn = 0.5 * 4 * T * self.num_attention_heads * self.head_dim * self.num_hidden_layers
+        return 2 * self.matmul_params() + attn
+
+    def lm_head_flops_per_row(self):
+        return 2.0 * self.hidden_size * self.vocab_size
+
 
 class _Holder(nn.Module):
     """Leaf module owning one HF-named ``weight`` Parameter (a view into the flat buffer)."""

@@ -8,6 +8,7 @@ DistillationLoss  ->  log {student_loss, teacher_loss, distill_loss} when
 ``state.global_step % args.logging_steps == 0``  ->  ``loss`` or ``(loss, outputs)``.
 """
 import os
+import time
 
 import torch
 from transformers import Trainer
@@ -29,7 +30,10 @@ class DistillationTrainer(Trainer):
         self.is_quantized_teacher = is_quantized_teacher
         # compute back-ends; the product ones are the HIP kernels (tests may inject a checker here)
         self._extract_topk = ops.logsoftmax_topk
+        # throughput of the loop: positions (B*T of every training micro-batch, padding included -- what the kernels
+        # process and what bench.py counts) seen by THIS rank; `log` turns it into whole-job tokens/sec
         self.tokens_seen = 0
+        self._tps_mark = None  # (perf_counter, tokens_seen) at the previous training log
         # The frozen teacher does not depend on the student: on GPUs its forward (+ top-K) runs on a second HIP
         # stream beside the student forward (+4.5 % step throughput on MI355X); results are identical.
         self.overlap_teacher = True
@@ -60,8 +64,22 @@ class DistillationTrainer(Trainer):
             return self._hip_dp
         return super()._wrap_model(model, training=training, dataloader=dataloader)
 
-    def create_optimizer(self):
-        """HF trainer.py `create_optimizer`: TrainingArguments' default is torch AdamW (the reference passes no
+    def log(self, logs, *args, **kwargs):
+        """train.py:107-114 logs the three sub-losses only; SURVEY section 8 f-1 asks the counterpart for tokens/sec.  HF's
+        own training log (the dict with ``loss`` / ``learning_rate``, every ``logging_steps`` optimizer steps, after a
+        ``.item()`` that has drained the GPU) gets ``tokens_per_second``: positions of all ranks' micro-batches since the
+        previous such log over the wall time between the two."""
+        if "loss" in logs and "learning_rate" in logs and self._tps_mark is not None:
+            now = time.perf_counter()
+            t0, n0 = self._tps_mark
+            if now > t0 and self.tokens_seen > n0:
+                logs = dict(logs)
+                logs["tokens_per_second"] = round((self.tokens_seen - n0) * max(1, self.args.world_size) / (now - t0), 1)
+            self._tps_mark = (now, self.tokens_seen)
+        return super().log(logs, *args, **kwargs)
+
+    def create_optimizer(self, model=None):
+        """HF trainer.py `create_optimizer(self, model=None)`: TrainingArguments' default is torch AdamW (the reference passes no
         ``optim``, train.py:331-354).  For a flat-buffer student on the GPU the same update -- same hyper-parameters,
         weight decay on matrices only like HF's parameter groups, moments in the parameters' dtype (quirk Q5) -- is ONE
         fused launch over the flat parameter / gradient / moment buffers (``sd_adamw_bf16``).  HF keeps clipping
@@ -74,7 +92,8 @@ class DistillationTrainer(Trainer):
             self.optimizer = FlatAdamW(core, lr=self.args.learning_rate, betas=(self.args.adam_beta1, self.args.adam_beta2),
                                        eps=self.args.adam_epsilon, weight_decay=self.args.weight_decay)
             return self.optimizer
-        return super().create_optimizer()
+        # (HF calls create_optimizer(model) on its delay_optimizer_creation path: FSDP / SageMaker model parallel)
+        return super().create_optimizer(model) if model is not None else super().create_optimizer()
 
     def _clip_grad_norm(self, model):
         """HF trainer.py:2535-2539 calls ``clip_grad_norm_`` over ~310 parameter tensors (10 ms of host time per
@@ -136,6 +155,18 @@ class DistillationTrainer(Trainer):
         teacher_top_k_i = inputs.pop("teacher_top_k_i", None)
 
         need_teacher = teacher_top_k_v is None and self.teacher_model is not None
+        ids0 = inputs.get("input_ids")
+        if (need_teacher and teacher_input_ids is not None and ids0 is not None
+                and tuple(teacher_input_ids.shape) != tuple(ids0.shape)):
+            # The collator pads teacher and student separately (data.py:219-278) and the loss indexes both with ONE
+            # [B, T-1] row mask (distillation_loss.py:31-45): the reference dies there with an IndexError.  Same
+            # condition, named, before any kernel indexes a [B, T_teacher] tensor with the student's T.
+            raise ValueError(f"teacher_input_ids {tuple(teacher_input_ids.shape)} and input_ids {tuple(ids0.shape)} must be "
+                             "position-aligned (data.py:20-60 align_prefixes): the loss selects rows of both with one mask")
+        if model.training and ids0 is not None:
+            self.tokens_seen += ids0.numel()
+            if self._tps_mark is None:
+                self._tps_mark = (time.perf_counter(), self.tokens_seen - ids0.numel())
         # `model` is what the loop trains (HipDataParallel / torch DDP / the bare module); `core` is the module itself
         core = ddp.unwrap(model)
         hip_student = isinstance(core, HipQwen3ForCausalLM)
@@ -149,12 +180,19 @@ class DistillationTrainer(Trainer):
         if (self.compact_head and not return_outputs and hip_student and lab is not None
                 and lab.is_cuda and isinstance(self.distill_loss_fn, DistillationLoss)):
             # the one host read of the step: the row count, and (same read) that the masks are right-padded
-            rows, row_labels = ops.loss_rows(lab, speech_mask, right_padded=(
-                inputs.get("attention_mask"), teacher_attention_mask if hip_teacher else None))
-            checked = {"padding_checked": True}
+            # only masks laid out on the labels' [B, T] grid go into the fused check; any other keeps its own validation
+            # in the model's forward (padding_checked stays unset for it)
+            am, tam = inputs.get("attention_mask"), (teacher_attention_mask if hip_teacher and need_teacher else None)
+            am = am if am is not None and tuple(am.shape) == tuple(lab.shape) else None
+            tam = tam if tam is not None and tuple(tam.shape) == tuple(lab.shape) else None
+            rows, row_labels = ops.loss_rows(lab, speech_mask, right_padded=(am, tam))
+            checked = {"padding_checked": True} if am is not None or inputs.get("attention_mask") is None else {}
+            teacher_checked = {"padding_checked": True} if tam is not None or teacher_attention_mask is None else {}
             if rows.numel() == 0:  # N == 0: the full path returns the reference's zeros (distillation_loss.py:47-53)
                 rows = row_labels = None
-        teacher_kw = checked if hip_teacher else {}
+        else:
+            teacher_checked = {}
+        teacher_kw = teacher_checked if hip_teacher else {}
         if (need_teacher and self.overlap_teacher and vocab is not None and ids is not None and ids.is_cuda
                 and hip_teacher):
             if self._teacher_stream is None:

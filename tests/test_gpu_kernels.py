@@ -663,6 +663,13 @@ def test_loss_rows_kernel_equals_the_reference_rule(ops, B, T):
             ops.loss_rows(to_dev(labels), None, right_padded=(to_dev(am), to_dev(bad)))
         # a float / bool mask is accepted too
         ops.loss_rows(to_dev(labels), to_dev(speech).bool(), right_padded=(to_dev(am).float(),))
+    # int32 labels keep their VALUES (token ids and -100), they are not read as a 0/1 mask
+    want_r, want_l = ops.loss_rows(labels, None)
+    got_r, got_l = ops.loss_rows(to_dev(labels.to(torch.int32)), None)
+    assert torch.equal(got_r.cpu(), want_r) and torch.equal(got_l.cpu(), want_l) and got_l.dtype == torch.int64
+    # a mask that is not on the labels' [B, T] grid (a teacher batch padded to another length) never reaches the kernel
+    with pytest.raises(ValueError, match="!= labels"):
+        ops.loss_rows(to_dev(labels), None, right_padded=(to_dev(am), to_dev(torch.ones(B, T + 3, dtype=torch.long))))
 
 
 def test_gradient_norm_reduction_is_bitwise_reproducible(ops):
@@ -682,3 +689,16 @@ def test_gradient_norm_reduction_is_bitwise_reproducible(ops):
     acc = torch.full((1,), 3.0, dtype=torch.float32, device=x.device)  # accumulates into `out`
     ops.sumsq(x, acc)
     assert abs(float(acc) - 3.0 - outs[0]) <= 1e-6 * outs[0]
+    # the partial sums live in the CALLER's scratch: two reductions in flight on two streams do not disturb each other
+    y = to_dev(bf(torch.randn(5_000_000, generator=g) * 3))
+    ref_y = float(y.double().pow(2).sum())
+    s2 = torch.cuda.Stream()
+    px, py = (torch.empty(2048, dtype=torch.float32, device=x.device) for _ in range(2))
+    for _ in range(10):
+        ox, oy = (torch.zeros(1, dtype=torch.float32, device=x.device) for _ in range(2))
+        s2.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s2):
+            ops.sumsq(y, oy, py)
+        ops.sumsq(x, ox, px)
+        torch.cuda.synchronize()
+        assert float(ox) == outs[0] and abs(float(oy) - ref_y) <= 1e-5 * ref_y

@@ -337,3 +337,34 @@ def test_hf_default_optimizer_still_works_and_agrees_with_the_fused_one(sda):
     assert abs(gn_f[0] - gn_h[0]) <= 1e-3 * gn_h[0]           # step 1: identical gradients, two routes to the same norm
     np.testing.assert_allclose(loss_f, loss_h, rtol=2e-2)     # bf16 moments either way; the updates differ by rounding
     np.testing.assert_allclose(gn_f, gn_h, rtol=5e-2)
+
+
+def test_teacher_batch_of_another_length_is_refused_on_the_gpu_path(sda):
+    """the collator pads teacher and student separately, so T_teacher can differ from T; the fused
+    row-selection kernel indexes every mask as [B, T] with the LABELS' T.  The trainer must refuse such a batch (the
+    reference dies in its loss with an IndexError, distillation_loss.py:31-45) before any kernel reads the short mask;
+    and HF's real training log carries tokens_per_second."""
+    from transformers import TrainingArguments
+    from speech_distill_amd.trainer import DistillationTrainer
+    z, st, te, sw, tw, feats, pad, bos = _c1(sda)
+    student, teacher = _build(sda, st, sw), _build(sda, te, tw)
+    teacher.eval().requires_grad_(False)
+    args = TrainingArguments(output_dir=tempfile.mkdtemp(), report_to=[], remove_unused_columns=False, label_names=["labels"],
+                             save_strategy="no", logging_steps=1, bf16=True)
+    tr = DistillationTrainer(model=student, args=args, teacher_model=teacher, temperature=2.0, alpha=0.5, top_k=16)
+    g = torch.Generator().manual_seed(0)
+    ids = torch.randint(0, 640, (2, 40), generator=g)
+    labels = ids.clone()
+    labels[:, :9] = -100
+    for dt in (-7, +5):
+        tids = torch.randint(0, 640, (2, 40 + dt), generator=g)
+        batch = {"input_ids": to_dev(ids), "attention_mask": to_dev(torch.ones_like(ids)), "labels": to_dev(labels),
+                 "teacher_input_ids": to_dev(tids), "teacher_attention_mask": to_dev(torch.ones_like(tids))}
+        with pytest.raises(ValueError, match="position-aligned"):
+            tr.compute_loss(student, batch)
+    # int32 labels (an arrow column read without a cast): same loss as int64 labels
+    base = {"input_ids": to_dev(ids), "attention_mask": to_dev(torch.ones_like(ids)),
+            "teacher_input_ids": to_dev(ids), "teacher_attention_mask": to_dev(torch.ones_like(ids))}
+    a = tr.compute_loss(student, dict(base, labels=to_dev(labels)))
+    b = tr.compute_loss(student, dict(base, labels=to_dev(labels.to(torch.int32))))
+    assert float(a) == float(b) and float(a) > 0
