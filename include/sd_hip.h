@@ -82,6 +82,21 @@ typedef struct {
   int32_t M, N;
 } sd_gemm_problem;
 int sd_gemm_grouped_tn(const sd_gemm_problem* probs, int n, int K, int accumulate, void* stream);
+/* The SAME forward projection of two independent models (student + frozen teacher in lockstep, train.py:54 and
+ * train.py:60-69 on one stream; or any two NT GEMMs) as ONE persistent launch: C_p [M,N] = A_p [M,K] . B_p [N,K]^T,
+ * p < n <= 2, K % 64 == 0.  nsplit > 1 cuts K into that many slices, each writing an fp32 slab [nsplit][M][N] into
+ * `slabs` (summed by the consumer, sd_rmsnorm_fwd_pair) instead of C.  swiglu != 0: B = [gate rows | up rows] [2I,K],
+ * N = 2I, act [M,I] = silu(gate) * up -> out2, gate|up -> C when C != NULL (HF:81-83), nsplit must be 1. */
+typedef struct {
+  const void* A;
+  const void* B;
+  void* C;
+  void* out2;
+  float* slabs;
+  int64_t lda, ldb, ldc;
+  int32_t M, N, K, nsplit;
+} sd_gemm_nt_problem;
+int sd_gemm_grouped_nt(const sd_gemm_nt_problem* probs, int n, int swiglu, void* stream);
 /* backward twin: d(gate|up) [M,2I] = SwiGLU'(gate_up) applied to d(act) = dy [M,H] . W_down [H,I], in the epilogue of
  * that GEMM (d(act) is never stored); equals sd_gemm_bf16 (NN) + sd_swiglu_bwd bit for bit. */
 int sd_gemm_swiglu_bwd(const void* dy, const void* wdown, const void* gate_up, void* dgate_up, int M, int I, int H,

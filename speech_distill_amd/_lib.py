@@ -35,6 +35,12 @@ class GemmProblem(C.Structure):
                 ("ldc", C.c_int64), ("M", C.c_int32), ("N", C.c_int32)]
 
 
+class GemmNtProblem(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p), ("out2", C.c_void_p), ("slabs", C.c_void_p),
+                ("lda", C.c_int64), ("ldb", C.c_int64), ("ldc", C.c_int64), ("M", C.c_int32), ("N", C.c_int32),
+                ("K", C.c_int32), ("nsplit", C.c_int32)]
+
+
 class ColsumProblem(C.Structure):
     _fields_ = [("partials", C.c_void_p), ("out", C.c_void_p), ("nb", C.c_int32), ("H", C.c_int32),
                 ("stride", C.c_int32), ("accumulate", C.c_int32)]
@@ -89,6 +95,7 @@ PROTOTYPES = {
     "sd_kdloss_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _i, _vp]),
     "sd_kdloss_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _i, _vp]),
     "sd_gemm_grouped_tn": (_i, [_vp, _i, _i, _i, _vp]),
+    "sd_gemm_grouped_nt": (_i, [_vp, _i, _i, _vp]),
     "sd_gemm_swiglu_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "sd_gemm_odx_delta": (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _i, _i, _i, _i, _vp]),
     "sd_kdloss_fwd_rows": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _vp]),

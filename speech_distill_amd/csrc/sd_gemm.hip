@@ -220,7 +220,7 @@ SD_DEV void epi_preload(EpiPre<EPI, BM, NTHR>& pre, const bf16* R, const EpiArgs
 
 template <int EPI, int BM, int NTHR>
 SD_DEV void write_out(const float* cs, bf16* C, const EpiPre<EPI, BM, NTHR>& pre, float* slabs, const EpiArgs& ea, int M,
-                      int N, long ldc, int m0, int n0, int tn) {
+                      int N, long ldc, int m0, int n0, int tn, int slice) {
 #pragma unroll
   for (int it = 0; it < BM * 16 / NTHR; ++it) {
     const int q = it * NTHR + threadIdx.x;
@@ -232,7 +232,7 @@ SD_DEV void write_out(const float* cs, bf16* C, const EpiPre<EPI, BM, NTHR>& pre
     float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     if constexpr (EPI == 2) {
       if (ok) {
-        float* dst = slabs + ((long)blockIdx.y * M + gm) * N + gn;
+        float* dst = slabs + ((long)slice * M + gm) * N + gn;
         *(f32x4*)dst = lo;
         *(f32x4*)(dst + 4) = hi;
       }
@@ -340,6 +340,18 @@ SD_DEV void tile_coords(int tile, int tiles_m, int tiles_n, int group_m, int& tm
   tm = g0 + (r - tn * gh);
 }
 
+// Which (tile, K slice) a workgroup of a (tiles, slices) grid takes.  The hardware deals workgroups to the 8 XCDs
+// round-robin by LINEAR id (x fastest), so remapping blockIdx.x alone -- as round 2 did -- leaves every XCD with a few
+// tiles of ALL the slices: for the gate|up dX (64 tiles x 4 slices) each 4 MiB L2 then streams 15.7 MB of operand
+// panels (272 MB per launch at the fabric against 71 MB algorithmic, profiles/r02_pmc_traffic.json).  Remapping the
+// linear id over tiles x slices gives an XCD's 32 resident workgroups ONE slice of a near-square block of tiles
+// (6.3 MB per XCD).  One slice: identical to the old order.  Speed only.
+SD_DEV void tile_and_slice(int ntiles, int& tile, int& slice) {
+  const int g = xcd_remap((int)blockIdx.x + (int)gridDim.x * (int)blockIdx.y, ntiles * (int)gridDim.y);
+  slice = g / ntiles;
+  tile = g - slice * ntiles;
+}
+
 // NST-deep LDS ring: tile t+NST-1 is issued while tile t is computed; the wait for tile t is a COUNTED
 // s_waitcnt vmcnt that leaves the NST-2 younger tiles in flight across the (raw) barrier.  Tiles past
 // the end of K are still issued (their lanes read the zero page), which keeps the count uniform.
@@ -360,7 +372,8 @@ __global__ __launch_bounds__(BM == 256 ? 512 : 256, (BM == 256 ? 2 : (NST * (BM 
   const int lane = lane_id();
   const int w = wave_id_uniform();
   const int wm = w >> 1, wn = w & 1;
-  const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  int tile, slice;
+  tile_and_slice(tiles_m * tiles_n, tile, slice);
   int tm, tn;
   tile_coords(tile, tiles_m, tiles_n, group_m, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
@@ -375,7 +388,7 @@ __global__ __launch_bounds__(BM == 256 ? 512 : 256, (BM == 256 ? 2 : (NST * (BM 
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int kt_all = (K + BK - 1) / BK;
-  const int kt0 = blockIdx.y * k_tiles_per_split;
+  const int kt0 = slice * k_tiles_per_split;
   const int kt1 = min(kt_all, kt0 + k_tiles_per_split);
   const int nk = kt1 - kt0;
   const int k_end = min(K, kt1 * BK);
@@ -450,7 +463,7 @@ __global__ __launch_bounds__(BM == 256 ? 512 : 256, (BM == 256 ? 2 : (NST * (BM 
     }
   }
   __syncthreads();
-  write_out<EPI, BM, NTHR>(cs, C, pre, slabs, ea, M, N, ldc, m0, n0, tn);
+  write_out<EPI, BM, NTHR>(cs, C, pre, slabs, ea, M, N, ldc, m0, n0, tn, slice);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -480,7 +493,8 @@ __global__ __launch_bounds__(512, 2) void gemm_stag_kernel(const bf16* __restric
   const int w = wave_id_uniform();
   const int wm = w >> 1, wn = w & 1;
   const int half = w >> 2;  // waves 0-3 / 4-7: one of each per SIMD
-  const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  int tile, slice;
+  tile_and_slice(tiles_m * tiles_n, tile, slice);
   int tm, tn;
   tile_coords(tile, tiles_m, tiles_n, group_m, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
@@ -495,7 +509,7 @@ __global__ __launch_bounds__(512, 2) void gemm_stag_kernel(const bf16* __restric
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int kt_all = (K + BK - 1) / BK;
-  const int kt0 = blockIdx.y * k_tiles_per_split;
+  const int kt0 = slice * k_tiles_per_split;
   const int kt1 = min(kt_all, kt0 + k_tiles_per_split);
   const int nk = kt1 - kt0;
   FastStage<TA, BM, NW> fa;
@@ -573,7 +587,7 @@ __global__ __launch_bounds__(512, 2) void gemm_stag_kernel(const bf16* __restric
     }
   }
   __syncthreads();
-  write_out<EPI, 256, 512>(cs, C, pre, slabs, ea, M, N, ldc, m0, n0, tn);
+  write_out<EPI, 256, 512>(cs, C, pre, slabs, ea, M, N, ldc, m0, n0, tn, slice);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1089,11 +1103,15 @@ struct GroupArgs {
   int n;
 };
 
-template <bool ACCUM>
+// SHARE: the compute waves issue 2 of the 48 LDS-DMA pieces of a stage each (the second half of A), as in gemm_pstag_kernel
+template <bool ACCUM, bool SHARE>
 __global__ __launch_bounds__(768) void gemm_pgroup_tn_kernel(GroupArgs ga, int K, int group_m) {
   constexpr int BM = 256, NW = 8, NPROD = 4, NST = 3, DEPTH = NST - 1;
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;  // 48 KiB
-  constexpr int LOADS = (BM + BN) / (8 * NPROD);
+  constexpr int A_PIECES = BM / 8, B_PIECES = BN / 8;
+  constexpr int CW = (A_PIECES / 2) / NW;
+  constexpr int PA = (SHARE ? A_PIECES / 2 : A_PIECES) / NPROD, PB = B_PIECES / NPROD;
+  constexpr int LOADS = PA + PB;
   constexpr int PATCH = 2048;
   __shared__ __attribute__((aligned(16))) char smem[NST * STAGE + NW * PATCH];
   const int lane = lane_id();
@@ -1116,15 +1134,16 @@ __global__ __launch_bounds__(768) void gemm_pgroup_tn_kernel(GroupArgs ga, int K
 
   if (w >= NW) {  // ------------------------------------------------------------ producer waves
     const int pw = w - NW;
-    FastStage<true, BM, NPROD> fa;
+    FastStage<true, BM, A_PIECES / PA> fa;  // pieces pw*PA .. +PA of the A tile (its first half when the compute waves share)
     FastStage<true, BN, NPROD> fb;
+    static_assert(FastStage<true, BM, A_PIECES / PA>::NI == PA && FastStage<true, BN, NPROD>::NI == PB, "piece split");
     int pf_tile = 0, pf_k = 0;
     unsigned pf_a = 0, pf_b = 0;
     (void)pf_a; (void)pf_b;
     auto pf_set = [&](int idx) {
       int p = 0, tm = 0, tn = 0;
       if (idx < my_tiles) locate(idx, p, tm, tn);
-      fa.init(ga.A[p], ga.lda[p], 0, (unsigned)(((long)(K - 1) * ga.lda[p] + ga.M[p]) * 2), pw, lane);
+      fa.init(ga.A[p], ga.lda[p], 0, (unsigned)(((long)(K - 1) * ga.lda[p] + ga.M[p]) * 2), pw, lane, 0, pw * PA);
       fb.init(ga.B[p], ga.ldb[p], 0, (unsigned)(((long)(K - 1) * ga.ldb[p] + ga.N[p]) * 2), pw, lane);
       pf_a = (unsigned)((long)tm * BM * 2);
       pf_b = (unsigned)((long)tn * BN * 2);
@@ -1134,9 +1153,8 @@ __global__ __launch_bounds__(768) void gemm_pgroup_tn_kernel(GroupArgs ga, int K
       const int sa = (int)(pf_a + (unsigned)(pf_k * BK) * (unsigned)fa.kstep);
       const int sb = (int)(pf_b + (unsigned)(pf_k * BK) * (unsigned)fb.kstep);
 #pragma unroll
-      for (int i = 0; i < FastStage<true, BM, NPROD>::NI; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(
-            fa.rsrc, (SD_LDS void*)(stage + (pw * FastStage<true, BM, NPROD>::NI + i) * 1024), 16, fa.voff[i], sa, 0, 0);
+      for (int i = 0; i < PA; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(fa.rsrc, (SD_LDS void*)(stage + (pw * PA + i) * 1024), 16, fa.voff[i], sa, 0, 0);
 #pragma unroll
       for (int i = 0; i < FastStage<true, BN, NPROD>::NI; ++i)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(
@@ -1171,12 +1189,42 @@ __global__ __launch_bounds__(768) void gemm_pgroup_tn_kernel(GroupArgs ga, int K
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  FastStage<true, BM, A_PIECES / CW> fc;
+  int cf_tile = 0, cf_k = 0, cnx_i = DEPTH;
+  unsigned cf_a = 0;
+  (void)cf_a; (void)cf_tile; (void)cf_k; (void)cnx_i;
+  auto cf_set = [&](int idx) {
+    int p = 0, tm = 0, tn = 0;
+    if (idx < my_tiles) locate(idx, p, tm, tn);
+    fc.init(ga.A[p], ga.lda[p], 0, (unsigned)(((long)(K - 1) * ga.lda[p] + ga.M[p]) * 2), w, lane, 0, A_PIECES / 2 + w * CW);
+    cf_a = (unsigned)((long)tm * BM * 2);
+  };
+  auto cf_issue = [&](char* stage) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int sa = (int)(cf_a + (unsigned)(cf_k * BK) * (unsigned)fc.kstep);
+#pragma unroll
+    for (int i = 0; i < CW; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(fc.rsrc, (SD_LDS void*)(stage + (A_PIECES / 2 + w * CW + i) * 1024), 16,
+                                               fc.voff[i], sa, 0, 0);
+#endif
+    if (++cf_k == nk) { cf_k = 0; cf_set(++cf_tile); }
+  };
+  if constexpr (SHARE) {
+    cf_set(0);
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) cf_issue(smem + d * STAGE);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
   __builtin_amdgcn_s_barrier();
   if (half == 1) __builtin_amdgcn_s_barrier();
 
   int cur_i = 0, ck = 0, ctile = 0;
   char* ep = smem + NST * STAGE + w * PATCH;
   for (int g = 0; g < total; ++g) {
+    if constexpr (SHARE) {
+      cf_issue(smem + cnx_i * STAGE);
+      cnx_i = (cnx_i == NST - 1) ? 0 : cnx_i + 1;
+    }
     const char* cur = smem + cur_i * STAGE;
     bf16x8 af[2][4], bfr[2][4];
 #pragma unroll
@@ -1184,6 +1232,7 @@ __global__ __launch_bounds__(768) void gemm_pgroup_tn_kernel(GroupArgs ga, int K
       load_frags_tr<BM, 4>(cur, wm * 64, kk, lane, af[kk]);
       load_frags_tr<BN, 4>(cur + A_BYTES, wn * 64, kk, lane, bfr[kk]);
     }
+    if constexpr (SHARE) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DEPTH - 1) * CW) : "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
@@ -1240,7 +1289,287 @@ __global__ __launch_bounds__(768) void gemm_pgroup_tn_kernel(GroupArgs ga, int K
     cur_i = (cur_i == NST - 1) ? 0 : cur_i + 1;
   }
   if (half == 0) __builtin_amdgcn_s_barrier();
+  if constexpr (SHARE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Grouped persistent NT kernel: the SAME forward projection of the student and of the frozen teacher (they are
+// independent, have the same token count and run in lockstep: sd_qwen3_forward_pair) as ONE stream of work.  Alone, the
+// N = hidden projections of a 2048-token micro-batch have 64-128 tiles of 256x128 -- a quarter to a half of the CUs --
+// and every launch pays its own ramp; together, and optionally cut along K (a slice writes an fp32 slab that the
+// following RMSNorm sums: sd_rmsnorm_fwd_pair), they fill the chip with the big tile.  Same 12-wave structure, ring and
+// hazard argument as gemm_pstag_kernel; a workgroup's unit list is built per XCD so that every XCD gets an equal share of
+// EACH problem (the problems differ in K, i.e. in cost per unit) and, at any time, its 32 workgroups hold consecutive
+// units of one problem and one slice (shared operand panels in its L2).
+//   EPI 0: C (bf16) or, for nsplit > 1, slabs[slice] (fp32) = A . B^T
+//   EPI 3: SwiGLU as in gemm_pstag_kernel (B tile = 64 gate rows | 64 up rows), act -> out2, gate|up -> C when C != null
+struct NtGroupArgs {  // structure of arrays, indexed by a readfirstlane'd problem number (stays in kernarg memory)
+  const bf16* A[2];
+  const bf16* B[2];
+  bf16* C[2];
+  bf16* out2[2];
+  float* slabs[2];
+  long lda[2], ldb[2], ldc[2];
+  int M[2], N[2], K[2], I[2];                      // N: GEMM columns (2I for EPI 3)
+  int tiles_m[2], tiles_n[2], nsplit[2], kt_per[2];  // kt_per: K-steps of a slice (the last may be shorter)
+  int n;
+};
+
+// A problem field by (wave-uniform) problem number p in {0, 1}, as ARITHMETIC on the two values: a runtime index into
+// the argument struct, or a ?: that the optimiser may turn into a select of addresses, makes hipcc keep a copy of the
+// struct in scratch memory and read every field back from there.
+SD_DEV int psel_v(int p, int v0, int v1) { return v0 ^ ((v0 ^ v1) & -p); }
+SD_DEV long psel_v(int p, long v0, long v1) { return v0 ^ ((v0 ^ v1) & -(long)p); }
+template <class T> SD_DEV T* psel_v(int p, T* v0, T* v1) {
+  return (T*)(uintptr_t)psel_v(p, (long)(uintptr_t)v0, (long)(uintptr_t)v1);
+}
+#define PSEL(F) psel_v(p, ga.F[0], ga.F[1])
+template <int EPI>
+__global__ __launch_bounds__(768) void gemm_pgroup_nt_kernel(NtGroupArgs ga, int group_m) {
+  static_assert(EPI == 0 || EPI == 3, "plain / slab or SwiGLU epilogue");
+  constexpr int BM = 256, NW = 8, NPROD = 4, NST = 3, DEPTH = NST - 1;
+  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;  // 48 KiB
+  // the LDS-DMA issue is shared as in gemm_pstag_kernel: the producers stage B and the first half of A, every compute
+  // wave CW pieces of the second half of A in its LOAD phase (producers alone: ~1.05 us per K-step instead of 0.8)
+  constexpr int A_PIECES = BM / 8, B_PIECES = BN / 8;
+  constexpr int CW = (A_PIECES / 2) / NW;
+  constexpr int PA = (A_PIECES / 2) / NPROD, PB = B_PIECES / NPROD;
+  constexpr int LOADS = PA + PB;
+  constexpr int PATCH = 2048;
+  __shared__ __attribute__((aligned(16))) char smem[NST * STAGE + NW * PATCH];
+  const int lane = lane_id();
+  const int w = wave_id_uniform();
+  // ---- this workgroup's units: XCD x = blockIdx.x & 7 owns units [ubase_p(x), ubase_p(x) + ucnt_p(x)) of problem p; its
+  // wpx workgroups walk "problem 0's share, then problem 1's" with stride wpx
+  const int xcd = (int)blockIdx.x & 7, jx = (int)blockIdx.x >> 3, wpx = (int)gridDim.x >> 3;
+  const int ntile0 = ga.tiles_m[0] * ga.tiles_n[0], ntile1 = ga.n > 1 ? ga.tiles_m[1] * ga.tiles_n[1] : 0;
+  const int U0 = ntile0 * ga.nsplit[0], U1 = ga.n > 1 ? ntile1 * ga.nsplit[1] : 0;
+  const int ucnt0 = (U0 >> 3) + (xcd < (U0 & 7) ? 1 : 0), ucnt1 = (U1 >> 3) + (xcd < (U1 & 7) ? 1 : 0);
+  const int ubase0 = xcd * (U0 >> 3) + (xcd < (U0 & 7) ? xcd : (U0 & 7));
+  const int ubase1 = xcd * (U1 >> 3) + (xcd < (U1 & 7) ? xcd : (U1 & 7));
+  const int my_len = ucnt0 + ucnt1;
+  const int my_units = jx < my_len ? (my_len - jx + wpx - 1) / wpx : 0;
+  // unit idx of this workgroup -> problem, tile, K slice
+  auto locate = [&](int idx, int& p, int& tm, int& tn, int& slice, int& kt0, int& nk) __attribute__((always_inline)) {
+    const int s = jx + idx * wpx;
+    p = __builtin_amdgcn_readfirstlane(s < ucnt0 ? 0 : 1);
+    const int g = psel_v(p, ubase0 + s, ubase1 + (s - ucnt0));
+    const int nt = psel_v(p, ntile0, ntile1);
+    slice = g / nt;
+    const int tile = g - slice * nt;
+    tile_coords(tile, PSEL(tiles_m), PSEL(tiles_n), group_m < PSEL(tiles_m) ? group_m : PSEL(tiles_m), tm, tn);
+    const int kt_all = (PSEL(K) + BK - 1) / BK;
+    kt0 = slice * PSEL(kt_per);
+    const int kt1 = kt0 + PSEL(kt_per) < kt_all ? kt0 + PSEL(kt_per) : kt_all;
+    nk = kt1 - kt0;
+  };
+  int total = 0;
+  for (int i = 0; i < my_units; ++i) {
+    int p, tm, tn, sl, k0, nk;
+    locate(i, p, tm, tn, sl, k0, nk);
+    total += nk;
+  }
+  if (my_units == 0) return;  // (uniform per workgroup: no barrier has been executed yet)
+
+  if (w >= NW) {  // ------------------------------------------------------------ producer waves: the operand stream
+    const int pw = w - NW;
+    FastStage<false, BM, A_PIECES / PA> fa;  // NI = PA pieces: pieces pw*PA .. of the first half of the A tile
+    FastStage<false, BN, NPROD> fb;
+    static_assert(FastStage<false, BM, A_PIECES / PA>::NI == PA && FastStage<false, BN, NPROD>::NI == PB, "piece split");
+    int pf_idx = 0, pf_k = 0, pf_nk = 1;
+    unsigned pf_a = 0, pf_b = 0;
+    (void)pf_a; (void)pf_b;
+    auto pf_set = [&](int idx) __attribute__((always_inline)) {
+      int p, tm, tn, sl, k0, nk;
+      locate(idx < my_units ? idx : 0, p, tm, tn, sl, k0, nk);
+      fa.init(PSEL(A), PSEL(lda), 0, (unsigned)(((long)(PSEL(M) - 1) * PSEL(lda) + PSEL(K)) * 2), pw, lane, 0, pw * PA);
+      fb.init(PSEL(B), PSEL(ldb), 0, (unsigned)(((long)(PSEL(N) - 1) * PSEL(ldb) + PSEL(K)) * 2), pw, lane,
+              EPI == 3 ? PSEL(I) - 64 : 0);
+      const long m0 = (long)tm * BM, nb0 = (EPI == 3) ? (long)tn * 64 : (long)tn * BN;
+      pf_a = (unsigned)((m0 * PSEL(lda) + (long)k0 * BK) * 2);
+      pf_b = (unsigned)((nb0 * PSEL(ldb) + (long)k0 * BK) * 2);
+      pf_nk = nk;
+    };
+    auto pf_issue = [&](char* stage) __attribute__((always_inline)) {
+#if defined(__HIP_DEVICE_COMPILE__)
+      const int sa = (int)(pf_a + (unsigned)(pf_k * BK * 2));
+      const int sb = (int)(pf_b + (unsigned)(pf_k * BK * 2));
+#pragma unroll
+      for (int i = 0; i < PA; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(fa.rsrc, (SD_LDS void*)(stage + (pw * PA + i) * 1024), 16, fa.voff[i], sa, 0, 0);
+#pragma unroll
+      for (int i = 0; i < PB; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(fb.rsrc, (SD_LDS void*)(stage + A_BYTES + (pw * PB + i) * 1024), 16, fb.voff[i],
+                                                 sb, 0, 0);
+#endif
+      if (++pf_k == pf_nk) { pf_k = 0; pf_set(++pf_idx); }
+    };
+    pf_set(0);
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) pf_issue(smem + d * STAGE);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    int nxt = DEPTH;
+    for (int g = 0; g < total; ++g) {
+      pf_issue(smem + nxt * STAGE);
+      nxt = (nxt == NST - 1) ? 0 : nxt + 1;
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DEPTH - 1) * LOADS) : "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_s_barrier();
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return;
+  }
+
+  // ---------------------------------------------------------------------------- compute waves
+  const int wm = w >> 1, wn = w & 1;
+  const int half = w >> 2;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // this wave's share of the operand stream: CW pieces of the second half of every A stage, issued in LOAD(g) for K-step
+  // g+DEPTH and retired by a counted vmcnt before the barrier that closes the phase (same RAW / WAR argument as the
+  // producers'; a finished unit's stores sit in the same in-order counter)
+  FastStage<false, BM, A_PIECES / CW> fc;
+  static_assert(FastStage<false, BM, A_PIECES / CW>::NI == CW, "piece split");
+  int cf_idx = 0, cf_k = 0, cf_nk = 1;
+  unsigned cf_a = 0;
+  (void)cf_a;
+  auto cf_set = [&](int idx) __attribute__((always_inline)) {
+    int p, tm, tn, sl, k0, nk;
+    locate(idx < my_units ? idx : 0, p, tm, tn, sl, k0, nk);
+    fc.init(PSEL(A), PSEL(lda), 0, (unsigned)(((long)(PSEL(M) - 1) * PSEL(lda) + PSEL(K)) * 2), w, lane, 0,
+            A_PIECES / 2 + w * CW);
+    cf_a = (unsigned)((((long)tm * BM) * PSEL(lda) + (long)k0 * BK) * 2);
+    cf_nk = nk;
+  };
+  auto cf_issue = [&](char* stage) __attribute__((always_inline)) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int sa = (int)(cf_a + (unsigned)(cf_k * BK * 2));
+#pragma unroll
+    for (int i = 0; i < CW; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(fc.rsrc, (SD_LDS void*)(stage + (A_PIECES / 2 + w * CW + i) * 1024), 16,
+                                               fc.voff[i], sa, 0, 0);
+#endif
+    if (++cf_k == cf_nk) { cf_k = 0; cf_set(++cf_idx); }
+  };
+  cf_set(0);
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) cf_issue(smem + d * STAGE);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (half == 1) __builtin_amdgcn_s_barrier();
+
+  int cur_i = 0, cnx_i = DEPTH, ck = 0, cunit = 0;
+  int cp, ctm, ctn, cslice, ckt0, cnk;
+  locate(0, cp, ctm, ctn, cslice, ckt0, cnk);
+  char* ep = smem + NST * STAGE + w * PATCH;
+  for (int g = 0; g < total; ++g) {
+    cf_issue(smem + cnx_i * STAGE);
+    cnx_i = (cnx_i == NST - 1) ? 0 : cnx_i + 1;
+    const char* cur = smem + cur_i * STAGE;
+    bf16x8 af[2][4], bfr[2][4];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[kk][i] = load_frag<false, BM>(cur, wm * 64 + i * 16, kk, lane);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        bfr[kk][j] = load_frag<false, BN>(cur + A_BYTES, EPI == 3 ? (j >> 1) * 64 + wn * 32 + (j & 1) * 16 : wn * 64 + j * 16, kk, lane);
+    }
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DEPTH - 1) * CW) : "memory");  // my pieces of K-step g+1 have landed
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(bfr[kk][j], af[kk][i], acc[i][j]);
+    __builtin_amdgcn_s_setprio(0);
+    if (++ck == cnk) {  // unit finished: this wave's 64 x 64 block leaves
+      ck = 0;
+      const int p = cp;
+      const int M = PSEL(M), N = PSEL(N);
+      const long ldc = PSEL(ldc);
+      bf16* const C = PSEL(C);
+      const int m0 = ctm * BM;
+      const int r = lane & 15, q4 = lane >> 4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int gm0 = m0 + wm * 64 + i * 16;
+        if constexpr (EPI == 3) {
+          const int gm = gm0 + r, I = PSEL(I);
+          bf16* const out2 = PSEL(out2);
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int gc = ctn * 64 + wn * 32 + j * 16 + q4 * 4;  // column of act; gate at gc, up at I + gc
+            bf16x4 a4, g4, u4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              // same rounding as the unfused pair: gate|up are rounded to bf16 first (sd_swiglu_fwd reads them back)
+              const bf16 gb = (bf16)acc[i][j][e], ub = (bf16)acc[i][j + 2][e];
+              const float gf = (float)gb, uf = (float)ub;
+              g4[e] = gb; u4[e] = ub;
+              a4[e] = (bf16)(gf / (1.f + __expf(-gf)) * uf);
+            }
+            if (gm < M && gc < I) {
+              *(bf16x4*)(out2 + (long)gm * I + gc) = a4;
+              if (C) {
+                *(bf16x4*)(C + (long)gm * ldc + gc) = g4;
+                *(bf16x4*)(C + (long)gm * ldc + I + gc) = u4;
+              }
+            }
+          }
+        } else if (PSEL(slabs)) {
+          // K slice: fp32 partial sums straight from the accumulators (16 rows x 64-byte pieces per instruction; the
+          // pieces of a 128-byte line meet in L2)
+          const int gn0 = ctn * BN + wn * 64 + q4 * 4;
+          float* dst = PSEL(slabs) + ((long)cslice * M + gm0 + r) * N + gn0;
+          if (gm0 + r < M) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (gn0 + j * 16 < N) *(f32x4*)(dst + j * 16) = acc[i][j];
+          }
+        } else {
+          const int gn0 = ctn * BN + wn * 64;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (bf16)acc[i][j][e];
+            *(bf16x4*)(ep + r * 128 + (((2 * j + (q4 >> 1)) ^ (r & 7)) << 4) + (q4 & 1) * 8) = o;
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh) {
+            const int rr = hh * 8 + (lane >> 3), cc = lane & 7;
+            const bf16x8 v = *(const bf16x8*)(ep + rr * 128 + ((cc ^ (rr & 7)) << 4));
+            const int gmr = gm0 + rr, gn = gn0 + cc * 8;
+            if (gmr < M && gn < N) *(bf16x8*)(C + (long)gmr * ldc + gn) = v;
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      if (++cunit < my_units) locate(cunit, cp, ctm, ctn, cslice, ckt0, cnk);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    cur_i = (cur_i == NST - 1) ? 0 : cur_i + 1;
+  }
+  if (half == 0) __builtin_amdgcn_s_barrier();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain my tail prefetches before the workgroup retires
+}
+#undef PSEL
 
 // ---------------------------------------------------------------------------------------------------
 // K-split staggered 64x128x64 kernel (8 waves) for GEMMs with few output tiles and a long K (N = hidden: o / down
@@ -1263,7 +1592,8 @@ __global__ __launch_bounds__(512, 2) void gemm_ks_kernel(const bf16* __restrict_
   const int w = wave_id_uniform();
   const int half = w >> 2, wh = w & 3;  // waves 0-3 / 4-7: one of each per SIMD
   const int wm = wh >> 1, wn = wh & 1;
-  const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  int tile, slice;
+  tile_and_slice(tiles_m * tiles_n, tile, slice);
   int tm, tn;
   tile_coords(tile, tiles_m, tiles_n, group_m, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
@@ -1279,7 +1609,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ks_kernel(const bf16* __restrict_
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int kt_all = (K + BK - 1) / BK;
-  const int kt0 = blockIdx.y * k_tiles_per_split;
+  const int kt0 = slice * k_tiles_per_split;
   const int kt1 = min(kt_all, kt0 + k_tiles_per_split);
   const int nk = kt1 - kt0;
   const int nkh = (nk + 1) >> 1;      // iterations of both halves
@@ -1376,7 +1706,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ks_kernel(const bf16* __restrict_
     }
   }
   __syncthreads();
-  write_out<EPI, 64, 512>(cs, C, pre, slabs, ea, M, N, ldc, m0, n0, tn);
+  write_out<EPI, 64, 512>(cs, C, pre, slabs, ea, M, N, ldc, m0, n0, tn, slice);
 }
 
 // C = sum_s slab[s] (+ R), fixed order
@@ -1619,7 +1949,8 @@ extern "C" int sd_gemm_splitk_plan(int M, int N, int K) {
   // The slice count that fills whole rounds of 256 workgroups best (fewest slices on a tie: every slice is another
   // fp32 slab; a slice keeps at least 24 K-steps).  48 tiles (lm_head dX on R = 1536 rows) -> 5 slices = 240
   // workgroups, not 8 = 384 = 1.5 rounds; 64 tiles -> 4.
-  const int cmax = kt / 24 < 8 ? kt / 24 : 8;
+  static const int min_slice = getenv("SD_SPLITK_MIN_SLICE") ? atoi(getenv("SD_SPLITK_MIN_SLICE")) : 24;  // A/B measurements
+  const int cmax = kt / min_slice < 8 ? kt / min_slice : 8;
   int s = 1;
   double best = (double)tiles / 256.0;
   for (int c = 2; c <= cmax; ++c) {
@@ -1692,12 +2023,58 @@ extern "C" int sd_gemm_grouped_tn(const sd_gemm_problem* probs, int n, int K, in
   if (cus <= 0) return SD_ERR_UNSUPPORTED;
   SdProfScope prof(SD_K_GEMM_TN, flops, (hipStream_t)stream);
   SD_PROF_LABEL("gemm_pgroup_tn_kernel<%s>", accumulate ? "true" : "false");
-  if (accumulate)
-    hipLaunchKernelGGL(gemm_pgroup_tn_kernel<true>, dim3(start < cus ? start : cus), dim3(768), 0, (hipStream_t)stream, ga,
-                       K, 4);
-  else
-    hipLaunchKernelGGL(gemm_pgroup_tn_kernel<false>, dim3(start < cus ? start : cus), dim3(768), 0, (hipStream_t)stream, ga,
-                       K, 4);
+  static const bool share = getenv("SD_TN_SHARE") ? atoi(getenv("SD_TN_SHARE")) != 0 : true;  // A/B measurements
+  const dim3 grid(start < cus ? start : cus);
+#define SD_TN_GO(ACC, SH) hipLaunchKernelGGL((gemm_pgroup_tn_kernel<ACC, SH>), grid, dim3(768), 0, (hipStream_t)stream, ga, K, 4)
+  if (accumulate) { if (share) SD_TN_GO(true, true); else SD_TN_GO(true, false); }
+  else { if (share) SD_TN_GO(false, true); else SD_TN_GO(false, false); }
+#undef SD_TN_GO
+  SD_CHECK_LAUNCH();
+  return 0;
+}
+
+// The same forward projection of two models (or any two independent NT GEMMs) as ONE persistent launch, see
+// gemm_pgroup_nt_kernel.  probs[i].nsplit > 1: fp32 slabs instead of C.  swiglu: EPI 3 (N = 2I, act -> out2).
+extern "C" int sd_gemm_grouped_nt(const sd_gemm_nt_problem* probs, int n, int swiglu, void* stream) {
+  if (n <= 0 || n > 2 || !probs) return SD_ERR_SHAPE;
+  NtGroupArgs ga{};
+  double flops = 0.0;
+  for (int p = 0; p < n; ++p) {
+    const sd_gemm_nt_problem& q = probs[p];
+    if (q.M <= 0 || q.N <= 0 || q.K <= 0 || (q.K % BK) || (q.N & 7) || ((q.lda | q.ldb | q.ldc) & 7)) return SD_ERR_UNSUPPORTED;
+    if (((uintptr_t)q.A | (uintptr_t)q.B | (uintptr_t)q.C | (uintptr_t)q.out2 | (uintptr_t)q.slabs) & 15) return SD_ERR_ALIGN;
+    if (((long)q.M * q.lda + q.K) * 2 >= 0x70000000L || ((long)q.N * q.ldb + q.K) * 2 >= 0x70000000L) return SD_ERR_UNSUPPORTED;
+    const int nsplit = q.nsplit < 1 ? 1 : q.nsplit;
+    if (swiglu && (nsplit != 1 || (q.N & 1) || ((q.N / 2) % 64) || !q.out2)) return SD_ERR_UNSUPPORTED;
+    if (!swiglu && nsplit > 1 && !q.slabs) return SD_ERR_WORKSPACE;
+    if (!swiglu && nsplit == 1 && !q.C) return SD_ERR_SHAPE;
+    ga.A[p] = (const bf16*)q.A; ga.B[p] = (const bf16*)q.B; ga.C[p] = (bf16*)q.C; ga.out2[p] = (bf16*)q.out2;
+    ga.slabs[p] = nsplit > 1 ? q.slabs : nullptr;
+    ga.lda[p] = q.lda; ga.ldb[p] = q.ldb; ga.ldc[p] = q.ldc;
+    ga.M[p] = q.M; ga.N[p] = q.N; ga.K[p] = q.K; ga.I[p] = swiglu ? q.N / 2 : 0;
+    ga.tiles_m[p] = (q.M + 255) / 256;
+    ga.tiles_n[p] = swiglu ? (ga.I[p] + 63) / 64 : (q.N + BN - 1) / BN;
+    const int kt_all = q.K / BK;
+    if (nsplit > kt_all) return SD_ERR_SHAPE;
+    ga.nsplit[p] = nsplit;
+    ga.kt_per[p] = (kt_all + nsplit - 1) / nsplit;
+    if ((long)ga.kt_per[p] * (nsplit - 1) >= kt_all) return SD_ERR_SHAPE;  // an empty last slice
+    flops += 2.0 * q.M * q.N * q.K;
+  }
+  ga.n = n;
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+    return SD_ERR_UNSUPPORTED;
+  cus &= ~7;
+  if (cus <= 0) return SD_ERR_UNSUPPORTED;
+  // a multiple of 8 workgroups, at most one per CU and no more than the busiest XCD's share needs
+  long per_xcd = 0;
+  for (int p = 0; p < n; ++p) per_xcd += ((long)ga.tiles_m[p] * ga.tiles_n[p] * ga.nsplit[p] + 7) / 8;
+  const int grid = (int)(per_xcd * 8 < cus ? per_xcd * 8 : cus);
+  SdProfScope prof(SD_K_GEMM_NT_STAG, flops, (hipStream_t)stream);
+  SD_PROF_LABEL("gemm_pgroup_nt_kernel<%d>", swiglu ? 3 : 0);
+  if (swiglu) hipLaunchKernelGGL(gemm_pgroup_nt_kernel<3>, dim3(grid), dim3(768), 0, (hipStream_t)stream, ga, 4);
+  else hipLaunchKernelGGL(gemm_pgroup_nt_kernel<0>, dim3(grid), dim3(768), 0, (hipStream_t)stream, ga, 4);
   SD_CHECK_LAUNCH();
   return 0;
 }

@@ -311,6 +311,37 @@ def gemm_grouped_tn(pairs, accumulate_into=None):
     return outs
 
 
+def gemm_grouped_nt(problems, swiglu=False):
+    """[(x [M,K], w [N,K], nsplit), ...] (at most 2) -> y_p = x_p @ w_p^T in ONE persistent launch (sd_gemm_grouped_nt).
+    nsplit > 1: the result comes back as fp32 slabs [nsplit, M, N] (un-reduced K slices) instead of a bf16 matrix.
+    swiglu: w_p = [gate rows | up rows] [2I,K]; returns (act [M,I], gate|up [M,2I]) per problem."""
+    from ._lib import GemmNtProblem
+    n = len(problems)
+    arr = (GemmNtProblem * n)()
+    outs = []
+    for i, (x, w, nsplit) in enumerate(problems):
+        _need(x, torch.bfloat16, "x"), _need(w, torch.bfloat16, "w")
+        M, K = x.shape
+        N = w.shape[0]
+        if w.shape[1] != K:
+            raise ValueError("gemm_grouped_nt: contraction mismatch")
+        c = out2 = slabs = None
+        if swiglu:
+            c = torch.empty(M, N, dtype=torch.bfloat16, device=x.device)
+            out2 = torch.empty(M, N // 2, dtype=torch.bfloat16, device=x.device)
+            outs.append((out2, c))
+        elif nsplit > 1:
+            slabs = torch.empty(nsplit, M, N, dtype=torch.float32, device=x.device)
+            outs.append(slabs)
+        else:
+            c = torch.empty(M, N, dtype=torch.bfloat16, device=x.device)
+            outs.append(c)
+        arr[i] = GemmNtProblem(x.data_ptr(), w.data_ptr(), _p(c), _p(out2), _p(slabs), x.stride(0), w.stride(0), N, M, N, K,
+                               int(nsplit))
+    check(load_lib().sd_gemm_grouped_nt(C.cast(arr, C.c_void_p), n, int(swiglu), _stream()), "sd_gemm_grouped_nt")
+    return outs
+
+
 def gemm_swiglu_bwd(dy, wdown, gate_up):
     """d(gate|up) [M,2I] from dy [M,h], W_down [h,I] (torch layout [out=h, in=I]) and the forward's gate|up."""
     _need(dy, torch.bfloat16, "dy")

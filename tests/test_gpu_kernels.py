@@ -233,6 +233,61 @@ def test_gemm_persistent_swiglu(ops):
     assert torch.equal(act, act_ref) and torch.equal(act2, act_ref)
 
 
+@pytest.mark.parametrize("shapes", [
+    [(300, 136, 128, 1), (300, 264, 64, 1)],            # ragged edges, different K and N per problem
+    [(2048, 1024, 1024, 1), (2048, 2048, 1024, 1)],     # o-projection pair shapes (K scaled down)
+    [(520, 256, 1536, 3), (520, 128, 768, 2)],          # K slices of unequal length (24 K-steps in 3, 12 in 2)
+    [(1000, 392, 640, 5)],                              # one problem, the last slice shorter
+])
+def test_gemm_grouped_nt_equals_separate_gemms(ops, shapes):
+    """sd_gemm_grouped_nt (two independent forward projections as ONE persistent launch, optional K slices into fp32
+    slabs) against sd_gemm_bf16 on each problem: unsplit -> the same accumulation order, bit-identical; K slices ->
+    exact on integer data, and the slab sum rounds to the separate GEMM's result within one bf16 step on random data."""
+    g = torch.Generator().manual_seed(len(shapes) * 1000 + shapes[0][0])
+    for integer in (True, False):
+        probs, refs = [], []
+        for (M, N, K, ns) in shapes:
+            if integer:
+                x = torch.randint(-3, 4, (M, K), generator=g).float()
+                w = torch.randint(-3, 4, (N, K), generator=g).float()
+                x[0] += 1.0
+            else:
+                x, w = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.1
+            x, w = to_dev(bf(x)), to_dev(bf(w))
+            probs.append((x, w, ns))
+            refs.append(ops.gemm(x, w))
+        outs = ops.gemm_grouped_nt(probs)
+        for (M, N, K, ns), got, ref in zip(shapes, outs, refs):
+            if ns == 1:
+                assert got.dtype == torch.bfloat16 and torch.equal(got, ref), (M, N, K, integer)
+            else:
+                assert got.shape == (ns, M, N) and got.dtype == torch.float32
+                tot = got.double().sum(0)
+                if integer:
+                    assert torch.equal(tot.float().bfloat16(), ref), (M, N, K)
+                    want = (probs[shapes.index((M, N, K, ns))][0].double() @ probs[shapes.index((M, N, K, ns))][1].double().T)
+                    assert torch.equal(tot, want)
+                else:
+                    check_close(f"grouped_nt_slabs_{M}x{N}x{K}/{ns}", tot, ref.double(), 8e-3, 3e-3)
+
+
+def test_gemm_grouped_nt_swiglu_pair(ops):
+    """The gate|up projections of two models + SwiGLU in one launch == sd_gemm_bf16 + sd_swiglu_fwd per model, bit for bit
+    (gate|up kept, as the student needs it for the backward)."""
+    g = torch.Generator().manual_seed(77)
+    probs, refs = [], []
+    for (M, K, I) in ((700, 256, 64 * 9), (700, 128, 64 * 5)):
+        x = to_dev(bf(torch.randn(M, K, generator=g)))
+        wgu = to_dev(bf(torch.randn(2 * I, K, generator=g) * 0.1))
+        gu = ops.gemm(x, wgu)
+        probs.append((x, wgu, 1))
+        refs.append((ops.swiglu_fwd(gu), gu))
+    for (act, gu), (act_ref, gu_ref) in zip(ops.gemm_grouped_nt(probs, swiglu=True), refs):
+        assert torch.equal(gu, gu_ref) and torch.equal(act, act_ref)
+    with pytest.raises(Exception):  # K must be a multiple of 64 (both operands K-contiguous: no zero fill past K)
+        ops.gemm_grouped_nt([(to_dev(bf(torch.randn(64, 72))), to_dev(bf(torch.randn(128, 72))), 1)])
+
+
 @pytest.mark.parametrize("bm,nst", [(0, 0), (64, 3), (128, 3), (256, 9)])
 def test_gemm_swiglu_bwd_epilogue_equals_the_separate_kernels(ops, bm, nst):
     """down-projection dX GEMM + SwiGLU backward in its epilogue == sd_gemm_bf16 (NN) + sd_swiglu_bwd, bit for bit."""
