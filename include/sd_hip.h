@@ -107,6 +107,11 @@ int sd_gemm_qkv_rope(const void* x, const void* wqkv, void* qkv_out, void* qk_ou
 
 /* ---- RMSNorm (HF:59-64).  rstd (fp32 [M], nullable in fwd) is saved for backward. */
 int sd_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int M, int H, float eps, void* stream);
+/* Residual + K-sliced projection + RMSNorm in one pass (HF:304-323): x_out = bf16(resid + sum_s slabs[s]) with slabs fp32
+ * [nsplit][M][H] as sd_gemm_grouped_nt leaves them (one rounding of the fp32 sum, as the residual epilogue of the unsplit
+ * GEMM); y = RMSNorm(x_out) * w, rstd as sd_rmsnorm_fwd. */
+int sd_rmsnorm_fwd_slabs(const float* slabs, int nsplit, const void* resid, const void* w, void* x_out, void* y, float* rstd,
+                         int M, int H, float eps, void* stream);
 int64_t sd_rmsnorm_bwd_workspace_bytes(int M, int H);
 /* dx = d(norm)/dx . dy (+ dres, nullable: the residual-stream gradient); dw (+)= sum_rows dy * xhat */
 int sd_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, const void* dres, void* dx,

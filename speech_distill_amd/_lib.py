@@ -72,6 +72,7 @@ PROTOTYPES = {
     "sd_gemm_splitk_workspace_bytes": (_i64, [_i, _i, _i]),
     "sd_gemm_bf16_splitk": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _i64, _i64, _i, _i, _vp, _i64, _vp]),
     "sd_rmsnorm_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
+    "sd_rmsnorm_fwd_slabs": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "sd_rmsnorm_bwd_workspace_bytes": (_i64, [_i, _i]),
     "sd_rmsnorm_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _vp]),
     "sd_gemm_swiglu": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),

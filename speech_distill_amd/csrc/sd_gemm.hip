@@ -896,6 +896,210 @@ __global__ __launch_bounds__(768) void gemm_pstag_kernel(const bf16* __restrict_
 #undef SD_STAMP_DUMP
 
 // ---------------------------------------------------------------------------------------------------
+// Persistent 256x128x64 kernel with ONE compute wave per SIMD (4 compute + 4 producer waves).  In gemm_pstag_kernel a
+// K-step is 2 x (LOAD phase | barrier | 32-MFMA phase | barrier): the two waves of a SIMD alternate, the matrix pipe
+// idles across four barriers per step and a 32-MFMA phase takes ~700 cycles beside the partner's LDS reads (stamps,
+// DESIGN.md section 8) -- 0.8 us per step for 0.52 us of MFMA.  Here a compute wave owns 64 rows x 128 columns of the
+// tile (128 accumulator registers) and software-pipelines ITSELF: while the 32 MFMAs of one half K-step run, the 12
+// fragment reads of the next half K-step are in flight into a second register set, so the wave's stream is MFMAs with
+// LDS reads in their shadows and ONE barrier per K-step (in the middle: "everybody has read stage g; stage g+1 has
+// landed").  Producer waves (one per SIMD, asleep at the barrier most of the time) issue every LDS-DMA and do all the
+// waiting on memory.
+//   step g, first half:   ds_read (g, kk=1) -> set 1   ||  32 MFMAs on set 0 (g, kk=0)      | lgkmcnt(0) | barrier
+//   step g, second half:  ds_read (g+1, kk=0) -> set 0 ||  32 MFMAs on set 1 (g, kk=1)      | lgkmcnt(0)
+// Hazards (ring of 3 stages, K-step x in stage x % 3):
+//   RAW  stage g+1 is first read in the second half of step g, after barrier(g); every producer passed a counted vmcnt
+//        for its pieces of K-step g+1 before arriving at barrier(g).
+//   WAR  K-step g+3 is written into stage g % 3 after barrier(g); the last reads of stage g (kk=1) completed
+//        (lgkmcnt(0)) before the readers arrived at barrier(g).
+//   EPI 0: C = A.B^T       EPI 3: SwiGLU (B tile = 64 gate rows | 64 up rows: gate and up of one output in one lane)
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_p1_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B, bf16* C, int M,
+                                                      int N, int K, long lda, long ldb, long ldc, int tiles_m, int tiles_n,
+                                                      int group_m, EpiArgs ea) {
+  static_assert(EPI == 0 || EPI == 3, "plain or SwiGLU epilogue");
+  constexpr int BM = 256, NC = 4, NPROD = 4, NST = 3;
+  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;  // 48 KiB
+  constexpr int LOADS = (BM + BN) / (8 * NPROD);                                          // 12 pieces per producer and stage
+  constexpr int PATCH = 4096;                                                             // per compute wave: 16 rows x 256 B
+  __shared__ __attribute__((aligned(16))) char smem[NST * STAGE + NC * PATCH];            // 160 KiB
+  const int lane = lane_id();
+  const int w = wave_id_uniform();
+  const int ntiles = tiles_m * tiles_n;
+  const int nk = K / BK;
+  const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int total = my_tiles * nk;
+  auto origin = [&](int idx, int& tm, int& tn) __attribute__((always_inline)) {
+    const int t = xcd_remap((int)blockIdx.x + idx * (int)gridDim.x, ntiles);
+    tile_coords(t, tiles_m, tiles_n, group_m, tm, tn);
+  };
+
+  if (w >= NC) {  // ------------------------------------------------------------ producer waves: the operand stream
+    const int pw = w - NC;
+    FastStage<false, BM, NPROD> fa;
+    FastStage<false, BN, NPROD> fb;
+    fa.init(A, lda, 0, (unsigned)(((long)(M - 1) * lda + K) * 2), pw, lane);
+    fb.init(B, ldb, 0, (unsigned)(((long)(N - 1) * ldb + K) * 2), pw, lane, EPI == 3 ? ea.I - 64 : 0);
+    int pf_tile = 0, pf_k = 0;
+    unsigned pf_a = 0, pf_b = 0;
+    (void)pf_a; (void)pf_b;
+    auto pf_set = [&](int idx) __attribute__((always_inline)) {
+      int tm = 0, tn = 0;
+      if (idx < my_tiles) origin(idx, tm, tn);
+      pf_a = (unsigned)(((long)tm * BM) * lda * 2);
+      pf_b = (unsigned)(((long)tn * (EPI == 3 ? 64 : BN)) * ldb * 2);
+    };
+    auto pf_issue = [&](char* stage) __attribute__((always_inline)) {
+#if defined(__HIP_DEVICE_COMPILE__)
+      const int sa = (int)(pf_a + (unsigned)(pf_k * BK * 2));
+      const int sb = (int)(pf_b + (unsigned)(pf_k * BK * 2));
+#pragma unroll
+      for (int i = 0; i < FastStage<false, BM, NPROD>::NI; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+            fa.rsrc, (SD_LDS void*)(stage + (pw * FastStage<false, BM, NPROD>::NI + i) * 1024), 16, fa.voff[i], sa, 0, 0);
+#pragma unroll
+      for (int i = 0; i < FastStage<false, BN, NPROD>::NI; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+            fb.rsrc, (SD_LDS void*)(stage + A_BYTES + (pw * FastStage<false, BN, NPROD>::NI + i) * 1024), 16, fb.voff[i],
+            sb, 0, 0);
+#endif
+      if (++pf_k == nk) { pf_k = 0; pf_set(++pf_tile); }
+    };
+    pf_set(0);
+#pragma unroll
+    for (int d = 0; d < NST; ++d) pf_issue(smem + d * STAGE);  // K-steps 0, 1, 2 (steps past the end are never read)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LOADS) : "memory");  // K-step 0 has landed
+    __builtin_amdgcn_s_barrier();                                     // B0
+    int nxt = 0;
+    for (int g = 0; g < total; ++g) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");  // K-step g+1 has landed (g+2 may be in flight)
+      __builtin_amdgcn_s_barrier();                                 // barrier(g): stage g % 3 is free
+      pf_issue(smem + nxt * STAGE);                                 // K-step g+3
+      nxt = (nxt == NST - 1) ? 0 : nxt + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the tail prefetches before the workgroup retires
+    return;
+  }
+
+  // ---------------------------------------------------------------------------- compute waves (one per SIMD)
+  f32x4 acc[4][8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // fragment (i-th 16-row block of my 64 rows | j-th 16-column block) of half K-step kk: rows are multiples of 16 apart,
+  // so the XOR swizzle term (row & 7 = lane & 7) is the same for all of them: one per-lane base per kk, the rest constants
+  const int fr = lane & 15;
+  const unsigned base0 = (unsigned)(((fr * 8) + ((0 * 4 + (lane >> 4)) ^ (fr & 7))) << 4);
+  const unsigned base1 = (unsigned)(((fr * 8) + ((1 * 4 + (lane >> 4)) ^ (fr & 7))) << 4);
+  auto read_set = [&](const char* stage, unsigned base, bf16x8 (&fa_)[4], bf16x8 (&fb_)[8]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fa_[i] = *(const bf16x8*)(stage + base + (w * 64 + i * 16) * 128);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) fb_[j] = *(const bf16x8*)(stage + A_BYTES + base + (j * 16) * 128);
+  };
+  auto mma_set = [&](const bf16x8 (&fa_)[4], const bf16x8 (&fb_)[8]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[i][j] = mfma16(fb_[j], fa_[i], acc[i][j]);
+  };
+  bf16x8 a0[4], b0[8], a1[4], b1[8];
+  __builtin_amdgcn_s_barrier();  // B0: K-step 0 has landed
+  read_set(smem, base0, a0, b0);
+  // (the waits on LDS reads are the BUILTIN s_waitcnt, 0xC07F = lgkmcnt(0) alone: hipcc's own wait insertion sees it; an
+  // asm wait is invisible to it and it then drains the reads just issued in front of the first MFMA of the next half)
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  int cur_i = 0, ck = 0, ctile = 0;
+  char* ep = smem + NST * STAGE + w * PATCH;
+  for (int g = 0; g < total; ++g) {
+    const char* cur = smem + cur_i * STAGE;
+    const int nxt_i = (cur_i == NST - 1) ? 0 : cur_i + 1;
+    const char* nxs = smem + nxt_i * STAGE;
+    // ---- first half: reads of (g, kk=1) fly under the MFMAs of (g, kk=0)
+    read_set(cur, base1, a1, b1);
+    __builtin_amdgcn_s_setprio(1);
+    mma_set(a0, b0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();  // barrier(g)
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- second half: reads of (g+1, kk=0) fly under the MFMAs of (g, kk=1)
+    read_set(nxs, base0, a0, b0);
+    __builtin_amdgcn_s_setprio(1);
+    mma_set(a1, b1);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_sched_barrier(0);
+    if (++ck == nk) {  // tile finished: this wave's 64 x 128 block leaves, clear, go on with the next tile
+      ck = 0;
+      int tm, tn;
+      origin(ctile++, tm, tn);
+      const int m0 = tm * BM;
+      const int r = lane & 15, q4 = lane >> 4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int gm0 = m0 + w * 64 + i * 16;
+        if constexpr (EPI == 3) {
+          // act columns tn*64 .. +63: gate in acc[i][0..3], up in acc[i][4..7] (same lane, same output)
+          bf16x4 a4[4], g4[4], u4[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const bf16 gb = (bf16)acc[i][j][e], ub = (bf16)acc[i][j + 4][e];
+              const float gf = (float)gb, uf = (float)ub;
+              g4[j][e] = gb; u4[j][e] = ub;
+              a4[j][e] = (bf16)(gf / (1.f + __expf(-gf)) * uf);
+            }
+          // three 16 x 64 images through the patch as whole 128-byte rows
+#pragma unroll
+          for (int which = 0; which < 3; ++which) {
+            if (which > 0 && !C) break;
+            const bf16x4(&o)[4] = which == 0 ? a4 : which == 1 ? g4 : u4;
+            bf16* dst = which == 0 ? ea.out2 : which == 1 ? C : C + ea.I;
+            const long ldd = which == 0 ? ea.ld2 : ldc;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) *(bf16x4*)(ep + r * 128 + (((2 * j + (q4 >> 1)) ^ (r & 7)) << 4) + (q4 & 1) * 8) = o[j];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+              const int rr = hh * 8 + (lane >> 3), cc = lane & 7;
+              const bf16x8 v = *(const bf16x8*)(ep + rr * 128 + ((cc ^ (rr & 7)) << 4));
+              const int gmr = gm0 + rr, gn = tn * 64 + cc * 8;
+              if (gmr < M && gn < ea.I) *(bf16x8*)(dst + (long)gmr * ldd + gn) = v;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          }
+        } else {
+          // 16 rows x 128 columns = 16 rows x 256 B through the patch, stored as whole rows (4 rows per instruction)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (bf16)acc[i][j][e];
+            *(bf16x4*)(ep + r * 256 + (((2 * j + (q4 >> 1)) ^ (r & 15)) << 4) + (q4 & 1) * 8) = o;
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+          for (int hh = 0; hh < 4; ++hh) {
+            const int rr = hh * 4 + (lane >> 4), cc = lane & 15;
+            const bf16x8 v = *(const bf16x8*)(ep + rr * 256 + ((cc ^ (rr & 15)) << 4));
+            const int gmr = gm0 + rr, gn = tn * BN + cc * 8;
+            if (gmr < M && gn < N) *(bf16x8*)(C + (long)gmr * ldc + gn) = v;
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    cur_i = nxt_i;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Persistent 256 x 256 kernel for the forward (NT) GEMMs with many output columns: lm_head (N = vocabulary) and gate|up.
 // Every kernel above is bound by the L2 -> LDS rate (one CU's LDS-DMA sustains ~59 GB/s), i.e. by FLOP per staged
 // byte, i.e. by tile area: 256 x 128 stages (256+128)*2 B per 2*256*128 FLOP of a k (85 FLOP/B, 0.81 us per 64-deep
@@ -1739,6 +1943,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 void* g_stamp_buffer = nullptr;  // diagnostic build: device buffer for the phase stamps of gemm_pstag_kernel
 #endif
 bool g_no_fast_stage = false;  // tests / A-B measurements: force the checked staging path
+bool g_force_p1 = false;       // tests / A-B measurements: gemm_p1_kernel where gemm_pstag_kernel would run (nst | 0x200)
 thread_local bool g_skip_reduce = false;  // set by sd_gemm_bf16_splitk_partial around its dispatch
 
 template <int BM, int NST, bool TA, bool TB>
@@ -1763,6 +1968,8 @@ int launch(const void* A, const void* B, void* C, const void* R, float* slabs, i
     return cus & ~7;
   }();
   static const bool p256_ok = !getenv("SD_GEMM_NO_P256");  // A/B measurements
+  static const bool p1_env = getenv("SD_GEMM_P1") && atoi(getenv("SD_GEMM_P1")) != 0;  // A/B: one compute wave per SIMD
+  const bool use_p1 = p1_env || g_force_p1;
   // Measured (tests/bench_p256.py, MI355X): the 256 x 256 kernel ties the 256 x 128 one on the lm_head class (544 vs
   // 557 us student, 924 vs 929 us teacher) and loses on gate|up (114 vs 93 us teacher, 37.6 vs 36.3 us student): both
   // settle at ~0.9 us per staged K-step whatever the bytes of the step, i.e. the loop is paced by the latency of the
@@ -1793,6 +2000,15 @@ int launch(const void* A, const void* B, void* C, const void* R, float* slabs, i
         SD_PROF_LABEL("gemm_p256_kernel<%d>", EPI);                                                                   \
         hipLaunchKernelGGL((gemm_p256_kernel<EPI>), dim3(grid2), dim3(512), 0, st, (const bf16*)A, (const bf16*)B,     \
                            (bf16*)C, M, N, K, lda, ldb, ldc, t_m, t_n, t_m < 8 ? t_m : 8, ea);                         \
+        break;                                                                                                         \
+      }                                                                                                                \
+    }                                                                                                                  \
+    if constexpr (BM == 256 && NST == 9 && !TA && !TB && (EPI == 0 || EPI == 3)) {                                   \
+      if (use_p1 && splits == 1 && !R && tiles_m * tiles_n > persist_grid && persist_grid > 0 && (K % BK) == 0 &&      \
+          (EPI != 3 || (ea.I % 64) == 0)) {                                                                            \
+        SD_PROF_LABEL("gemm_p1_kernel<%d>", EPI);                                                                      \
+        hipLaunchKernelGGL((gemm_p1_kernel<EPI>), dim3(persist_grid), dim3(512), 0, st, (const bf16*)A, (const bf16*)B, \
+                           (bf16*)C, M, N, K, lda, ldb, ldc, tiles_m, tiles_n, gm, ea);                                \
         break;                                                                                                         \
       }                                                                                                                \
     }                                                                                                                  \
@@ -1933,6 +2149,7 @@ extern "C" void sd_debug_stamp_buffer(void* p) { g_stamp_buffer = p; }
 
 extern "C" void sd_gemm_force_variant(int bm, int nst) {
   g_no_fast_stage = (nst & 0x100) != 0;  // nst | 0x100: checked (pointer) staging instead of buffer descriptors
+  g_force_p1 = (nst & 0x200) != 0;       // nst | 0x200: the one-compute-wave-per-SIMD persistent kernel
   nst &= 0xff;
   g_force_variant = bm ? (bm | (nst << 16)) : 0;
 }

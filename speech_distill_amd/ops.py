@@ -124,6 +124,19 @@ def rmsnorm_fwd(x, w, eps=1e-6):
     return y, rstd
 
 
+def rmsnorm_fwd_slabs(slabs, resid, w, eps=1e-6):
+    """x = bf16(resid + sum of the fp32 K-slice slabs [nsplit,M,H]); returns (x, RMSNorm(x) * w, rstd)."""
+    _need(resid, torch.bfloat16, "resid"), _need(w, torch.bfloat16, "w")
+    if not slabs.is_cuda or slabs.dtype != torch.float32 or not slabs.is_contiguous() or slabs.shape[1:] != resid.shape:
+        raise ValueError("slabs: contiguous fp32 GPU tensor [nsplit, M, H]")
+    M, H = resid.shape
+    x, y = torch.empty_like(resid), torch.empty_like(resid)
+    rstd = torch.empty(M, dtype=torch.float32, device=resid.device)
+    check(load_lib().sd_rmsnorm_fwd_slabs(slabs.data_ptr(), slabs.shape[0], resid.data_ptr(), w.data_ptr(), x.data_ptr(),
+                                          y.data_ptr(), rstd.data_ptr(), M, H, eps, _stream()), "sd_rmsnorm_fwd_slabs")
+    return x, y, rstd
+
+
 def rmsnorm_bwd(dy, x, w, rstd, dres=None, dw=None, accumulate=False):
     M, H = x.shape
     lib = load_lib()
