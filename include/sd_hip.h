@@ -14,7 +14,7 @@
  *     (1) a pool of timing-disabled hipEvent_t sets, leased per sd_qwen3_backward* / sd_attn_bwd2 call and per device (two
  *     concurrent backward calls never share an event); (2) the sd_prof_* accumulators (only between
  *     sd_prof_begin/end); (3) measurement switches meant for tests and benchmarks, not for production use:
- *     sd_gemm_force_variant() and the environment variables SD_OVERLAP_MASK, SD_FUSE_STUDENT_SWIGLU, SD_GEMM_NO_P256,
+ *     sd_gemm_force_variant(), sd_debug_cu_budget() and the environment variables SD_OVERLAP_MASK, SD_FUSE_STUDENT_SWIGLU, SD_GEMM_NO_P256,
  *     SD_GEMM_P256_MIN_TILES, SD_GEMM_NO_PERSIST, SD_GEMM_GROUP_M, SD_TOPK_NT (A/B switches, each read once);
  *   - return value: SD_OK (0), a negative SD_ERR_* code, or a positive hipError_t from the launch.
  */
@@ -97,6 +97,8 @@ typedef struct {
   int32_t M, N, K, nsplit;
 } sd_gemm_nt_problem;
 int sd_gemm_grouped_nt(const sd_gemm_nt_problem* probs, int n, int swiglu, void* stream);
+/* measurements only (tests/bench_partition.py): cap the workgroups of every later sd_gemm_grouped_nt launch (0 = one per CU) */
+void sd_debug_cu_budget(int cus);
 /* backward twin: d(gate|up) [M,2I] = SwiGLU'(gate_up) applied to d(act) = dy [M,H] . W_down [H,I], in the epilogue of
  * that GEMM (d(act) is never stored); equals sd_gemm_bf16 (NN) + sd_swiglu_bwd bit for bit. */
 int sd_gemm_swiglu_bwd(const void* dy, const void* wdown, const void* gate_up, void* dgate_up, int M, int I, int H,

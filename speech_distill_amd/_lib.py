@@ -97,6 +97,7 @@ PROTOTYPES = {
     "sd_kdloss_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _i, _vp]),
     "sd_gemm_grouped_tn": (_i, [_vp, _i, _i, _i, _vp]),
     "sd_gemm_grouped_nt": (_i, [_vp, _i, _i, _vp]),
+    "sd_debug_cu_budget": (None, [_i]),
     "sd_gemm_swiglu_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "sd_gemm_odx_delta": (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _i, _i, _i, _i, _vp]),
     "sd_kdloss_fwd_rows": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _vp]),

@@ -1944,6 +1944,7 @@ void* g_stamp_buffer = nullptr;  // diagnostic build: device buffer for the phas
 #endif
 bool g_no_fast_stage = false;  // tests / A-B measurements: force the checked staging path
 bool g_force_p1 = false;       // tests / A-B measurements: gemm_p1_kernel where gemm_pstag_kernel would run (nst | 0x200)
+int g_cu_budget = 0;           // EXPERIMENT: workgroups a persistent grouped launch may use (0 = every CU)
 thread_local bool g_skip_reduce = false;  // set by sd_gemm_bf16_splitk_partial around its dispatch
 
 template <int BM, int NST, bool TA, bool TB>
@@ -2147,6 +2148,8 @@ extern "C" int sd_gemm_bf16(const void* A, const void* B, void* C, const void* R
 extern "C" void sd_debug_stamp_buffer(void* p) { g_stamp_buffer = p; }
 #endif
 
+extern "C" void sd_debug_cu_budget(int cus) { g_cu_budget = cus; }
+
 extern "C" void sd_gemm_force_variant(int bm, int nst) {
   g_no_fast_stage = (nst & 0x100) != 0;  // nst | 0x100: checked (pointer) staging instead of buffer descriptors
   g_force_p1 = (nst & 0x200) != 0;       // nst | 0x200: the one-compute-wave-per-SIMD persistent kernel
@@ -2240,7 +2243,9 @@ extern "C" int sd_gemm_grouped_tn(const sd_gemm_problem* probs, int n, int K, in
   if (cus <= 0) return SD_ERR_UNSUPPORTED;
   SdProfScope prof(SD_K_GEMM_TN, flops, (hipStream_t)stream);
   SD_PROF_LABEL("gemm_pgroup_tn_kernel<%s>", accumulate ? "true" : "false");
-  static const bool share = getenv("SD_TN_SHARE") ? atoi(getenv("SD_TN_SHARE")) != 0 : true;  // A/B measurements
+  // A/B (tests/bench_grouped.py, MI355X): sharing the DMA issue with the compute waves is 2-4 % SLOWER here (73.5-74.6 vs
+  // 76.3-78.3 us for a student layer's four weight gradients), unlike gemm_pstag_kernel's +3 %: off by default
+  static const bool share = getenv("SD_TN_SHARE") ? atoi(getenv("SD_TN_SHARE")) != 0 : false;
   const dim3 grid(start < cus ? start : cus);
 #define SD_TN_GO(ACC, SH) hipLaunchKernelGGL((gemm_pgroup_tn_kernel<ACC, SH>), grid, dim3(768), 0, (hipStream_t)stream, ga, K, 4)
   if (accumulate) { if (share) SD_TN_GO(true, true); else SD_TN_GO(true, false); }
@@ -2287,6 +2292,7 @@ extern "C" int sd_gemm_grouped_nt(const sd_gemm_nt_problem* probs, int n, int sw
   // a multiple of 8 workgroups, at most one per CU and no more than the busiest XCD's share needs
   long per_xcd = 0;
   for (int p = 0; p < n; ++p) per_xcd += ((long)ga.tiles_m[p] * ga.tiles_n[p] * ga.nsplit[p] + 7) / 8;
+  if (g_cu_budget > 0 && (g_cu_budget & ~7) < cus) cus = g_cu_budget & ~7;
   const int grid = (int)(per_xcd * 8 < cus ? per_xcd * 8 : cus);
   SdProfScope prof(SD_K_GEMM_NT_STAG, flops, (hipStream_t)stream);
   SD_PROF_LABEL("gemm_pgroup_nt_kernel<%d>", swiglu ? 3 : 0);

@@ -179,6 +179,69 @@ def test_gemm_persistent_kernel(ops, ta, tb, K):
 
 
 @pytest.mark.parametrize("K", [64, 192, 1088])
+def test_gemm_one_wave_per_simd_kernel_is_bit_identical(ops, K):
+    """gemm_p1_kernel (4 compute waves, one per SIMD, fragments double-buffered in registers, one barrier per K-step; reached
+    with sd_gemm_force_variant(0, 0x200)) against the persistent staggered kernel it would replace: the same K order per
+    accumulator, so plain and SwiGLU outputs are bit-identical; exact on integer data against fp64."""
+    g = torch.Generator().manual_seed(K + 7)
+    M, I = 1100, 64 * 37   # 5 x 37 tiles of 256x128 > 256 workgroups: the persistent path; M and N with ragged edges
+    lib = ops.load_lib()
+    x = torch.randint(-3, 4, (M, K), generator=g).float()
+    w = torch.randint(-3, 4, (2 * I, K), generator=g).float()
+    x[0] += 1.0
+    xd, wd = to_dev(bf(x)), to_dev(bf(w))
+    xr, wr = to_dev(bf(torch.randn(M, K, generator=g))), to_dev(bf(torch.randn(2 * I, K, generator=g) * 0.1))
+    try:
+        lib.sd_gemm_force_variant(0, 0)
+        ops.prof_begin()
+        ref_i, ref_r = ops.gemm(xd, wd), ops.gemm(xr, wr)
+        ref_a, ref_gu = ops.gemm_swiglu(xr, wr)
+        ops.prof_end()
+        base_syms = set(ops.prof_symbols())
+        lib.sd_gemm_force_variant(0, 0x200)
+        ops.prof_begin()
+        got_i, got_r = ops.gemm(xd, wd), ops.gemm(xr, wr)
+        got_a, got_gu = ops.gemm_swiglu(xr, wr)
+        got_a2, _ = ops.gemm_swiglu(xr, wr, save_gu=False)
+        ops.prof_end()
+        syms = set(ops.prof_symbols())
+    finally:
+        lib.sd_gemm_force_variant(0, 0)
+    assert any(s.startswith("gemm_p1_kernel<0>") for s in syms) and any(s.startswith("gemm_p1_kernel<3>") for s in syms), syms
+    assert not any(s.startswith("gemm_p1_kernel") for s in base_syms)
+    assert torch.equal(got_i.float().cpu(), (x.double() @ w.double().T).float().bfloat16().float())
+    assert torch.equal(got_i, ref_i) and torch.equal(got_r, ref_r)
+    assert torch.equal(got_a, ref_a) and torch.equal(got_gu, ref_gu) and torch.equal(got_a2, ref_a)
+
+
+def test_rmsnorm_fwd_slabs_equals_residual_gemm_then_norm(ops):
+    """sd_rmsnorm_fwd_slabs(K-slice slabs, residual) == [residual epilogue of the unsplit GEMM] + sd_rmsnorm_fwd: with one
+    slab the sums are the same fp32 numbers (bit-identical x, y, rstd); with K slices the fp32 sum is re-associated
+    (x within one bf16 step of the unsplit result, y / rstd accordingly)."""
+    g = torch.Generator().manual_seed(12)
+    M, N, K = 300, 1024, 1536
+    x = to_dev(bf(torch.randn(M, K, generator=g)))
+    w = to_dev(bf(torch.randn(N, K, generator=g) * 0.05))
+    r = to_dev(bf(torch.randn(M, N, generator=g)))
+    gain = to_dev(bf(1 + 0.2 * torch.randn(N, generator=g)))
+    x_ref = ops.gemm(x, w, residual=r)
+    y_ref, rstd_ref = ops.rmsnorm_fwd(x_ref, gain)
+    acc = (x.double() @ w.double().T)
+    one = acc.float().unsqueeze(0).contiguous()  # "one slab" = the exact fp32-rounded product
+    x1, y1, rstd1 = ops.rmsnorm_fwd_slabs(one, r, gain)
+    want_x = (acc.float() + r.float()).bfloat16()
+    assert torch.equal(x1, want_x)
+    y_w, rstd_w = ops.rmsnorm_fwd(want_x, gain)
+    assert torch.equal(y1, y_w) and torch.equal(rstd1, rstd_w)
+    for ns in (2, 3):
+        slabs = ops.gemm_grouped_nt([(x, w, ns)])[0]
+        xs, ys, rs = ops.rmsnorm_fwd_slabs(slabs, r, gain)
+        check_close(f"norm_slabs_x_{ns}", xs, x_ref, 8e-3, 2e-3)
+        check_close(f"norm_slabs_y_{ns}", ys, y_ref, 1.6e-2, 3e-3)
+        check_close(f"norm_slabs_rstd_{ns}", rs, rstd_ref, 2e-3)
+
+
+@pytest.mark.parametrize("K", [64, 192, 1088])
 def test_gemm_persistent_256x256_kernel(ops, K):
     """Forward (NT) GEMMs with >= 150 tiles of 256x256 take gemm_p256_kernel (BK = 32 stages, 8 waves, 64x128 per wave):
     K of 2, 6 and 34 steps per tile, ragged M and N edges, one K stream across tile boundaries; must equal the
