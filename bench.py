@@ -362,7 +362,7 @@ def main():
             res["kernel_ms_per_step_sum"] = tot_ms / args.steps
             res["profiled_pass_ms_per_step"] = 1e3 * prof_dt / args.steps
             # ONE dominant kernel symbol (named as rocprofv3 --kernel-trace prints it, a row of
-            # profiles/r02_bench_serial_kernel_stats.csv); the kind it belongs to is given beside it as `family`
+            # profiles/r03_bench_serial_kernel_stats.csv); the kind it belongs to is given beside it as `family`
             dom = max(syms, key=lambda k: syms[k][0])
             ms, work, cnt, kind = syms[dom]
             fam_ms, fam_work, fam_cnt = prof[kind]
@@ -381,7 +381,19 @@ def main():
                            "achieved": fam_work / (fam_ms * 1e-3) / (1e12 if mfma else 1e9)},
                 "by_symbol_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in
                                           sorted(syms.items(), key=lambda kv: -kv[1][0])[:12]}}
-        pmc = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+            if mfma and dom.startswith(("gemm_pstag_kernel", "gemm_stag_kernel", "gemm_pgroup", "gemm_p1_kernel")):
+                # What actually paces a 256x128x64 tile loop is the operand stream into LDS, not the matrix pipe: every
+                # 2*256*128*64 FLOP stage (256+128)*64*2 B through the CU's L2 -> LDS path, whose measured ceiling is 66-73
+                # GB/s per CU (MI355X_MICROARCH.md, "Indexed rows: gather into LDS"; x 256 CUs).  Reported beside the MFMA
+                # fraction so that the binding roofline is visible: bytes staged per launch / launch duration.
+                staged = work / (2.0 * 256 * 128 * 64) * (256 + 128) * 64 * 2
+                res["roofline"]["operand_stream"] = {
+                    "bound": "l2_to_lds", "achieved": staged / (ms * 1e-3) / 1e9, "peak": 70.0 * 256, "unit": "GB/s",
+                    "frac": staged / (ms * 1e-3) / 1e9 / (70.0 * 256), "bytes_staged_per_launch_avg": staged / cnt,
+                    "note": "tile 256x128x64: 11.7 B staged per kFLOP, so 17.9 TB/s of LDS fill caps this tile shape at "
+                            "1.53 PFLOP/s whatever the loop structure (gemm_p1_kernel, a different structure, runs at the "
+                            "same speed: tests/bench_p1.py)"}
+        pmc = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
         if "roofline" in res and os.path.exists(pmc):
             try:  # HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
                 t = json.load(open(pmc))
