@@ -184,7 +184,7 @@ def test_gemm_one_wave_per_simd_kernel_is_bit_identical(ops, K):
     with sd_gemm_force_variant(0, 0x200)) against the persistent staggered kernel it would replace: the same K order per
     accumulator, so plain and SwiGLU outputs are bit-identical; exact on integer data against fp64."""
     g = torch.Generator().manual_seed(K + 7)
-    M, I = 1100, 64 * 37   # 5 x 37 tiles of 256x128 > 256 workgroups: the persistent path; M and N with ragged edges
+    M, I = 1000, 64 * 70   # 4 x 70 tiles of 256x128 > 256 workgroups: the persistent path; ragged M edge
     lib = ops.load_lib()
     x = torch.randint(-3, 4, (M, K), generator=g).float()
     w = torch.randint(-3, 4, (2 * I, K), generator=g).float()
@@ -192,13 +192,13 @@ def test_gemm_one_wave_per_simd_kernel_is_bit_identical(ops, K):
     xd, wd = to_dev(bf(x)), to_dev(bf(w))
     xr, wr = to_dev(bf(torch.randn(M, K, generator=g))), to_dev(bf(torch.randn(2 * I, K, generator=g) * 0.1))
     try:
-        lib.sd_gemm_force_variant(0, 0)
+        lib.sd_gemm_force_variant(256, 9)
         ops.prof_begin()
         ref_i, ref_r = ops.gemm(xd, wd), ops.gemm(xr, wr)
         ref_a, ref_gu = ops.gemm_swiglu(xr, wr)
         ops.prof_end()
         base_syms = set(ops.prof_symbols())
-        lib.sd_gemm_force_variant(0, 0x200)
+        lib.sd_gemm_force_variant(256, 9 | 0x200)
         ops.prof_begin()
         got_i, got_r = ops.gemm(xd, wd), ops.gemm(xr, wr)
         got_a, got_gu = ops.gemm_swiglu(xr, wr)
