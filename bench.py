@@ -383,16 +383,18 @@ def main():
                                           sorted(syms.items(), key=lambda kv: -kv[1][0])[:12]}}
             if mfma and dom.startswith(("gemm_pstag_kernel", "gemm_stag_kernel", "gemm_pgroup", "gemm_p1_kernel")):
                 # What actually paces a 256x128x64 tile loop is the operand stream into LDS, not the matrix pipe: every
-                # 2*256*128*64 FLOP stage (256+128)*64*2 B through the CU's L2 -> LDS path, whose measured ceiling is 66-73
-                # GB/s per CU (MI355X_MICROARCH.md, "Indexed rows: gather into LDS"; x 256 CUs).  Reported beside the MFMA
-                # fraction so that the binding roofline is visible: bytes staged per launch / launch duration.
+                # 2*256*128*64 FLOP stage (256+128)*64*2 B through the CU's LDS-DMA path.  Its ceiling under this very
+                # access pattern, with NO compute at all, is 63.3 GB/s per CU = 16.2 TB/s (tests/bench_dma_rate.py: 12-16
+                # issuing waves, any ring depth; the guide's 66-73 GB/s per CU is for an L2-resident gather).  Reported
+                # beside the MFMA fraction so that the binding roofline is visible: bytes staged / launch duration.
                 staged = work / (2.0 * 256 * 128 * 64) * (256 + 128) * 64 * 2
                 res["roofline"]["operand_stream"] = {
-                    "bound": "l2_to_lds", "achieved": staged / (ms * 1e-3) / 1e9, "peak": 70.0 * 256, "unit": "GB/s",
-                    "frac": staged / (ms * 1e-3) / 1e9 / (70.0 * 256), "bytes_staged_per_launch_avg": staged / cnt,
-                    "note": "tile 256x128x64: 11.7 B staged per kFLOP, so 17.9 TB/s of LDS fill caps this tile shape at "
-                            "1.53 PFLOP/s whatever the loop structure (gemm_p1_kernel, a different structure, runs at the "
-                            "same speed: tests/bench_p1.py)"}
+                    "bound": "lds_dma_fill", "achieved": staged / (ms * 1e-3) / 1e9, "peak": 63.3 * 256, "unit": "GB/s",
+                    "frac": staged / (ms * 1e-3) / 1e9 / (63.3 * 256), "bytes_staged_per_launch_avg": staged / cnt,
+                    "note": "tile 256x128x64: 11.7 B staged per kFLOP, so 16.2 TB/s of LDS fill caps this tile shape at "
+                            "1.38 PFLOP/s whatever the loop structure (gemm_p1_kernel, a different structure, runs at the "
+                            "same speed: tests/bench_p1.py); peak = the no-compute fill rate measured with the GEMM's own "
+                            "panel sharing (tests/bench_dma_rate.py)"}
         pmc = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
         if "roofline" in res and os.path.exists(pmc):
             try:  # HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
