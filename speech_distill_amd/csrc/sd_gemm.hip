@@ -1117,12 +1117,29 @@ __global__ __launch_bounds__(512) void gemm_p1_kernel(const bf16* __restrict__ A
 // A workgroup walks its tiles as ONE K stream (the tile origin is a scalar offset of the buffer load); a finished
 // 16 x 64 block leaves through the wave's 2 KiB LDS patch as whole 128-byte lines.
 //   EPI 0: C = A.B^T     EPI 3: SwiGLU, B tile = 128 gate rows | 128 up rows: gate and up of one output sit in one lane.
-template <int EPI>
+// PAIR (round 3): the 32-deep stages above fetch every 128-byte line of an operand row TWICE -- a stage's row is 64 B, half a
+// line, and the other half is requested again one K-step later, long after the 32 KiB L1 has turned over: the PMC pass
+// counts 92.2 M L1->L2 requests per lm_head launch for 46 M lines (profiles/r03_pmc_operand_stream.json), i.e. the kernel
+// sat at the 16 TB/s L2->L1 ceiling with half of it wasted.  With PAIR the ring is two slots of 64 KiB, each holding
+// BOTH 32-deep halves of a 64-deep K range: a 1 KiB DMA piece is 8 rows x 128 B of the operand (lanes 0-31 the first
+// k-half, lanes 32-63 the second: whole lines, one request each) and lands as [8 rows x 64 B | 8 rows x 64 B]; the
+// fragment reads of step g take half g & 1 of slot (g >> 1) & 1.  A slot is refilled during the EVEN step after its
+// last use (A pieces in the LOAD phase, B pieces at the head of the COMPUTE phase) and waited for (vmcnt(0)) in the odd
+// step's LOAD phase, one full step before its first read.  Measured (tests/bench_p256_pair.py): half the L2 requests,
+// identical results, 1.7 % faster (teacher lm_head 885.8 -> 870.8 us, student 497.2 -> 488.8 us): the kernel is paced by
+// its LOAD / COMPUTE phase structure, not by the L2 -> L1 rate it no longer saturates.
+//   RAW  super-stage q+1 (steps 2q+2, 2q+3) is first read in phase 4q+4; every wave waits vmcnt(0) in its LOAD(2q+1)
+//        (phases 4q+2 / 4q+3) and passes a barrier.
+//   WAR  slot (q+1)&1 is refilled from phase 4q on; its last reads (step 2q-1) were issued in phases 4q-2 / 4q-1 and
+//        completed (lgkmcnt(0)) before those phases' closing barriers.
+template <int EPI, bool PAIR>
 __global__ __launch_bounds__(512) void gemm_p256_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B, bf16* C, int M,
                                                         int N, int K, long lda, long ldb, long ldc, int tiles_m,
                                                         int tiles_n, int group_m, EpiArgs ea) {
   static_assert(EPI == 0 || EPI == 3, "plain or SwiGLU epilogue");
   constexpr int BM = 256, BNN = 256, NW = 8, NST = 4, DEPTH = NST - 1;
+  constexpr int SLOT = 2 * (BM + BNN) * P2_BK * 2, SLOT_A = 2 * BM * P2_BK * 2;  // PAIR: 64 KiB per slot, 32 KiB of it A
+  constexpr int NIP = 2 * BM * P2_BK * 2 / 1024 / NW;                            // PAIR: 4 pieces of A and 4 of B per wave and slot
   constexpr int A_BYTES = BM * P2_BK * 2, STAGE = (BM + BNN) * P2_BK * 2;  // 16 / 32 KiB
   constexpr int NI = BM * P2_BK * 2 / 1024 / NW;                           // 2 pieces of A and 2 of B per wave and K-step
   constexpr int LOADS = 2 * NI;
@@ -1140,13 +1157,23 @@ __global__ __launch_bounds__(512) void gemm_p256_kernel(const bf16* __restrict__
     tile_coords(t, tiles_m, tiles_n, group_m, tm, tn);
   };
   // ---- LDS-DMA of this wave: loop-invariant per-lane offsets, the tile origin and k are scalar
-  int voff_a[NI], voff_b[NI];
+  int voff_a[PAIR ? NIP : NI], voff_b[PAIR ? NIP : NI];
+  if constexpr (PAIR) {
 #pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    const int p = (w * NI + i) * 64 + lane;
-    const int r = p >> 2, c = (p & 3) ^ swz32(r);
-    voff_a[i] = (int)(((long)r * lda + c * 8) * 2);
-    voff_b[i] = (int)(((long)(r + ((EPI == 3 && r >= 128) ? ea.I - 128 : 0)) * ldb + c * 8) * 2);
+    for (int i = 0; i < NIP; ++i) {
+      const int blk = w * NIP + i;  // 8 rows of the 256-row operand tile
+      const int r = blk * 8 + ((lane & 31) >> 2), kh = lane >> 5, c = (lane & 3) ^ swz32(r);
+      voff_a[i] = (int)(((long)r * lda + kh * P2_BK + c * 8) * 2);
+      voff_b[i] = (int)(((long)(r + ((EPI == 3 && r >= 128) ? ea.I - 128 : 0)) * ldb + kh * P2_BK + c * 8) * 2);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int p = (w * NI + i) * 64 + lane;
+      const int r = p >> 2, c = (p & 3) ^ swz32(r);
+      voff_a[i] = (int)(((long)r * lda + c * 8) * 2);
+      voff_b[i] = (int)(((long)(r + ((EPI == 3 && r >= 128) ? ea.I - 128 : 0)) * ldb + c * 8) * 2);
+    }
   }
 #if defined(__HIP_DEVICE_COMPILE__)
   const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)(((long)(M - 1) * lda + K) * 2), 0x00020000);
@@ -1167,23 +1194,42 @@ __global__ __launch_bounds__(512) void gemm_p256_kernel(const bf16* __restrict__
   auto pf_issue_a = [&](char* stage) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const int sa = (int)(pf_a + (unsigned)(pf_k * P2_BK * 2));
+    if constexpr (PAIR) {
 #pragma unroll
-    for (int i = 0; i < NI; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (SD_LDS void*)(stage + (w * NI + i) * 1024), 16, voff_a[i], sa, 0, 0);
+      for (int i = 0; i < NIP; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (SD_LDS void*)(stage + (w * NIP + i) * 1024), 16, voff_a[i], sa, 0, 0);
+    } else {
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (SD_LDS void*)(stage + (w * NI + i) * 1024), 16, voff_a[i], sa, 0, 0);
+    }
 #endif
   };
   auto pf_issue_b = [&](char* stage) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const int sb = (int)(pf_b + (unsigned)(pf_k * P2_BK * 2));
+    if constexpr (PAIR) {
 #pragma unroll
-    for (int i = 0; i < NI; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (SD_LDS void*)(stage + A_BYTES + (w * NI + i) * 1024), 16, voff_b[i], sb, 0, 0);
+      for (int i = 0; i < NIP; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (SD_LDS void*)(stage + SLOT_A + (w * NIP + i) * 1024), 16, voff_b[i], sb, 0, 0);
+      pf_k += 2;  // a slot covers two 32-deep K-steps (nk is even: K % 64 == 0)
+      if (pf_k >= nk) { pf_k = 0; pf_set(++pf_tile); }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (SD_LDS void*)(stage + A_BYTES + (w * NI + i) * 1024), 16, voff_b[i], sb, 0, 0);
+      if (++pf_k == nk) { pf_k = 0; pf_set(++pf_tile); }
+    }
 #endif
-    if (++pf_k == nk) { pf_k = 0; pf_set(++pf_tile); }
   };
   pf_set(0);
+  if constexpr (PAIR) {
+    pf_issue_a(smem);
+    pf_issue_b(smem);
+  } else {
 #pragma unroll
-  for (int d = 0; d < DEPTH; ++d) { pf_issue_a(smem + d * STAGE); pf_issue_b(smem + d * STAGE); }
+    for (int d = 0; d < DEPTH; ++d) { pf_issue_a(smem + d * STAGE); pf_issue_b(smem + d * STAGE); }
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
@@ -1211,26 +1257,50 @@ __global__ __launch_bounds__(512) void gemm_p256_kernel(const bf16* __restrict__
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the patch is rewritten by the next block
   };
   int cur_i = 0, nxt_i = DEPTH, ck = 0, ctile = 0;
+  // PAIR: fragment (16 rows from row16_base, k-half kh) of the slot image: blocks of 8 rows, [8 x 64 B half 0 | 8 x 64 B half 1]
+  auto load_frag_pair = [&](const char* opnd, int row16_base, int kh) __attribute__((always_inline)) {
+    const int r = row16_base + (lane & 15), c = lane >> 4;
+    return *(const bf16x8*)(opnd + (r >> 3) * 1024 + kh * 512 + (r & 7) * 64 + ((c ^ swz32(r)) << 4));
+  };
   for (int g = 0; g < total; ++g) {
     // ---- LOAD(g)
-    pf_issue_a(smem + nxt_i * STAGE);
-    const char* cur = smem + cur_i * STAGE;
     bf16x8 af[4], bfr[8];
+    if constexpr (PAIR) {
+      const int kh = g & 1, slot = (g >> 1) & 1;
+      if (kh == 0) pf_issue_a(smem + (slot ^ 1) * SLOT);  // the other slot's last reads ended a full step ago
+      const char* cur = smem + slot * SLOT;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) af[i] = load_frag32(cur, wm * 64 + i * 16, lane);
+      for (int i = 0; i < 4; ++i) af[i] = load_frag_pair(cur, wm * 64 + i * 16, kh);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int brow = (EPI == 3) ? (j >> 2) * 128 + wn * 64 + (j & 3) * 16 : wn * 128 + j * 16;
-      bfr[j] = load_frag32(cur + A_BYTES, brow, lane);
+      for (int j = 0; j < 8; ++j) {
+        const int brow = (EPI == 3) ? (j >> 2) * 128 + wn * 64 + (j & 3) * 16 : wn * 128 + j * 16;
+        bfr[j] = load_frag_pair(cur + SLOT_A, brow, kh);
+      }
+      // odd step: everything this wave staged for the next slot (issued during the even step) has landed
+      if (kh == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      pf_issue_a(smem + nxt_i * STAGE);
+      const char* cur = smem + cur_i * STAGE;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = load_frag32(cur, wm * 64 + i * 16, lane);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int brow = (EPI == 3) ? (j >> 2) * 128 + wn * 64 + (j & 3) * 16 : wn * 128 + j * 16;
+        bfr[j] = load_frag32(cur + A_BYTES, brow, lane);
+      }
+      // issued so far, youngest first: A(g+3), B(g+2), A(g+2), B(g+1), ...: K-step g+1 has landed when all but 3*NI are done
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NI) : "memory");
     }
-    // issued so far, youngest first: A(g+3), B(g+2), A(g+2), B(g+1), ...: K-step g+1 has landed when all but 3*NI are done
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NI) : "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     // ---- COMPUTE(g)
-    pf_issue_b(smem + nxt_i * STAGE);
+    if constexpr (PAIR) {
+      if ((g & 1) == 0) pf_issue_b(smem + (((g >> 1) & 1) ^ 1) * SLOT);
+    } else {
+      pf_issue_b(smem + nxt_i * STAGE);
+    }
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -1944,6 +2014,7 @@ void* g_stamp_buffer = nullptr;  // diagnostic build: device buffer for the phas
 #endif
 bool g_no_fast_stage = false;  // tests / A-B measurements: force the checked staging path
 bool g_force_p1 = false;       // tests / A-B measurements: gemm_p1_kernel where gemm_pstag_kernel would run (nst | 0x200)
+bool g_force_p256_unpaired = false;  // tests / A-B measurements: the 32-deep-stage form of gemm_p256_kernel (nst | 0x400)
 int g_cu_budget = 0;           // EXPERIMENT: workgroups a persistent grouped launch may use (0 = every CU)
 thread_local bool g_skip_reduce = false;  // set by sd_gemm_bf16_splitk_partial around its dispatch
 
@@ -1969,6 +2040,8 @@ int launch(const void* A, const void* B, void* C, const void* R, float* slabs, i
     return cus & ~7;
   }();
   static const bool p256_ok = !getenv("SD_GEMM_NO_P256");  // A/B measurements
+  static const bool p256_pair_env = !(getenv("SD_GEMM_P256_PAIR") && atoi(getenv("SD_GEMM_P256_PAIR")) == 0);  // A/B
+  const bool p256_pair = p256_pair_env && !g_force_p256_unpaired;
   static const bool p1_env = getenv("SD_GEMM_P1") && atoi(getenv("SD_GEMM_P1")) != 0;  // A/B: one compute wave per SIMD
   const bool use_p1 = p1_env || g_force_p1;
   // Measured (tests/bench_p256.py, MI355X): the 256 x 256 kernel ties the 256 x 128 one on the lm_head class (544 vs
@@ -1998,9 +2071,15 @@ int launch(const void* A, const void* B, void* C, const void* R, float* slabs, i
           (N % 8) == 0 && nt2 >= p256_min_tiles && 10 * nt2 >= 7 * rounds * persist_grid && span < 0x7fffffffL &&      \
           span_b < 0x7fffffffL) {                                                                                     \
         const int grid2 = nt2 > persist_grid ? persist_grid : nt2;                                                    \
-        SD_PROF_LABEL("gemm_p256_kernel<%d>", EPI);                                                                   \
-        hipLaunchKernelGGL((gemm_p256_kernel<EPI>), dim3(grid2), dim3(512), 0, st, (const bf16*)A, (const bf16*)B,     \
-                           (bf16*)C, M, N, K, lda, ldb, ldc, t_m, t_n, t_m < 8 ? t_m : 8, ea);                         \
+        if (p256_pair && (K % (2 * P2_BK)) == 0) {                                                                    \
+          SD_PROF_LABEL("gemm_p256_kernel<%d, true>", EPI);                                                           \
+          hipLaunchKernelGGL((gemm_p256_kernel<EPI, true>), dim3(grid2), dim3(512), 0, st, (const bf16*)A,             \
+                             (const bf16*)B, (bf16*)C, M, N, K, lda, ldb, ldc, t_m, t_n, t_m < 8 ? t_m : 8, ea);        \
+        } else {                                                                                                       \
+          SD_PROF_LABEL("gemm_p256_kernel<%d, false>", EPI);                                                          \
+          hipLaunchKernelGGL((gemm_p256_kernel<EPI, false>), dim3(grid2), dim3(512), 0, st, (const bf16*)A,            \
+                             (const bf16*)B, (bf16*)C, M, N, K, lda, ldb, ldc, t_m, t_n, t_m < 8 ? t_m : 8, ea);        \
+        }                                                                                                              \
         break;                                                                                                         \
       }                                                                                                                \
     }                                                                                                                  \
@@ -2153,6 +2232,7 @@ extern "C" void sd_debug_cu_budget(int cus) { g_cu_budget = cus; }
 extern "C" void sd_gemm_force_variant(int bm, int nst) {
   g_no_fast_stage = (nst & 0x100) != 0;  // nst | 0x100: checked (pointer) staging instead of buffer descriptors
   g_force_p1 = (nst & 0x200) != 0;       // nst | 0x200: the one-compute-wave-per-SIMD persistent kernel
+  g_force_p256_unpaired = (nst & 0x400) != 0;  // nst | 0x400: gemm_p256_kernel with 32-deep half-line stages
   nst &= 0xff;
   g_force_variant = bm ? (bm | (nst << 16)) : 0;
 }

@@ -243,9 +243,11 @@ def test_rmsnorm_fwd_slabs_equals_residual_gemm_then_norm(ops):
 
 @pytest.mark.parametrize("K", [64, 192, 1088])
 def test_gemm_persistent_256x256_kernel(ops, K):
-    """Forward (NT) GEMMs with >= 150 tiles of 256x256 take gemm_p256_kernel (BK = 32 stages, 8 waves, 64x128 per wave):
-    K of 2, 6 and 34 steps per tile, ragged M and N edges, one K stream across tile boundaries; must equal the
-    128x128 kernel bit for bit (same accumulation order over k); run twice (race screen)."""
+    """Forward (NT) GEMMs with >= 150 tiles of 256x256 take gemm_p256_kernel (8 waves, 64x128 per wave): K of 2, 6 and 34
+    32-deep steps per tile, ragged M and N edges, one K stream across tile boundaries; must equal the 128x128 kernel bit
+    for bit (same accumulation order over k); run twice (race screen).  The default is the paired form (two slots of
+    64 KiB holding both 32-deep halves of whole 128-byte lines); sd_gemm_force_variant(0, 0x400) runs the 32-deep half-line
+    stages of round 2: both are checked."""
     g = torch.Generator().manual_seed(100 + K)
     M, N = 1000, 256 * 60 + 40
     a = bf(torch.randn(M, K, generator=g))
@@ -255,12 +257,18 @@ def test_gemm_persistent_256x256_kernel(ops, K):
     ops.prof_begin()
     outs = [ops.gemm(ad, bd), ops.gemm(ad, bd)]
     ops.prof_end()
-    assert any(k.startswith("gemm_p256_kernel<0>") for k in ops.prof_symbols()), ops.prof_symbols()
-    lib.sd_gemm_force_variant(128, 3)
+    assert any(k.startswith("gemm_p256_kernel<0, true>") for k in ops.prof_symbols()), ops.prof_symbols()
+    lib.sd_gemm_force_variant(0, 0x400)
     try:
+        ops.prof_begin()
+        outs.append(ops.gemm(ad, bd))
+        ops.prof_end()
+        assert any(k.startswith("gemm_p256_kernel<0, false>") for k in ops.prof_symbols()), ops.prof_symbols()
+        lib.sd_gemm_force_variant(128, 3)
         other = ops.gemm(ad, bd)
     finally:
         lib.sd_gemm_force_variant(0, 0)
+    assert torch.equal(outs[0], outs[2])
     check_close(f"gemm_p256_K{K}", outs[0], _gemm_ref(a.float(), b.float(), False, False), 6e-3, 3e-3)
     assert torch.equal(outs[0], outs[1])
     assert torch.equal(outs[0], other)
@@ -290,7 +298,7 @@ def test_gemm_persistent_swiglu(ops):
     ops.prof_begin()
     act, gu = ops.gemm_swiglu(x, wgu)
     ops.prof_end()
-    assert any(k.startswith("gemm_p256_kernel<3>") for k in ops.prof_symbols()), ops.prof_symbols()  # 5 x 45 tiles of 256x256
+    assert any(k.startswith("gemm_p256_kernel<3, true>") for k in ops.prof_symbols()), ops.prof_symbols()  # 5 x 45 tiles of 256x256
     act2, none = ops.gemm_swiglu(x, wgu, save_gu=False)
     assert torch.equal(gu, gu_ref) and none is None
     assert torch.equal(act, act_ref) and torch.equal(act2, act_ref)
