@@ -173,6 +173,9 @@ int sd_rows_scatter(const void* src, const int64_t* rows, void* dst, int n, int 
 int sd_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const int32_t* kv_len, int64_t ldq,
                 int64_t ldk, int64_t ldv, int64_t ldo, int B, int T, int Hq, int Hkv, int head_dim, float scale,
                 void* stream);
+/* measurements / tests only: the forward kernel without (bit 0) / with (bit 1) the in-wave software pipeline at any T
+ * (default: with it from T = 1024); both give the same results bit for bit */
+void sd_attn_force_variant(int variant);
 /* delta: fp32 [B,Hq,T] scratch (rowsum(dO*O)).  sd_attn_bwd2: same, with the dQ kernel launched on `side_stream`
  * (nullable) beside the dK/dV kernel -- they only share read-only inputs; `stream` has joined when it returns. */
 int sd_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse,

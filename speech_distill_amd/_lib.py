@@ -89,6 +89,7 @@ PROTOTYPES = {
     "sd_embedding_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "sd_embedding_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _vp]),
     "sd_attn_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _i, _f, _vp]),
+    "sd_attn_force_variant": (None, [_i]),
     "sd_attn_bwd": (_i, [_vp] * 11 + [_i64] * 7 + [_i, _i, _i, _i, _i, _f, _vp]),
     "sd_attn_bwd2": (_i, [_vp] * 11 + [_i64] * 7 + [_i, _i, _i, _i, _i, _f, _vp, _vp]),
     "sd_logsoftmax_topk": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _i, _i, _vp]),

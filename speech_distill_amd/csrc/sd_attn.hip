@@ -16,6 +16,7 @@
 // dK/dV kernel: S = Q K^T with the key on the lane; a wave owns 32 keys and keeps dK^T, dV^T in
 //   registers over all query tiles and all G query heads of its kv head (no atomics, deterministic):
 //   dV^T = dO^T P, dK^T = Q^T dS.
+#include <type_traits>
 #include "sd_common.cuh"
 #include "../../include/sd_hip.h"
 #include "sd_prof.h"
@@ -111,6 +112,15 @@ SD_DEV void tr_finish4(sd_u64 (&raw)[8], bf16x8 (&out)[4]) {
   lds_tr_wait8(raw);
 #pragma unroll
   for (int db = 0; db < 4; ++db) out[db] = cat8_u64(raw[2 * db], raw[2 * db + 1]);
+}
+
+// max of a value and the one the lane 32 away holds (v_permlane32_swap: one instruction, no LDS round trip).  As asm:
+// hipcc folds fmaxf(pr[0], pr[1]) of __builtin_amdgcn_permlane32_swap(u, u, ..) to pr[0] (it takes the two results of a
+// swap of equal operands for equal), which silently leaves every row with the maximum of its first lane half only.
+SD_DEV float halves_max(float x) {
+  float a = x, b = x;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 0" : "+v"(a), "+v"(b));  // a = lo|lo, b = hi|hi
+  return fmaxf(a, b);
 }
 
 SD_DEV bf16x8 acc_frag(const f32x16& p, int s) {
@@ -408,6 +418,247 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const bf16* __restrict__ 
   // every lane of a row has the same `inv` only after the two column halves are combined: lanes r and r+32 hold the
   // same row, and `l` was just summed over them, so scaling per lane before the transposing store is exact
   ATT_STAMP();  // 2+4nkv+1: merged
+  if (!active) return;
+  store_tile_rows((char*)xo, o, inv, O + (tok0 + q0w) * ldo + hq * D, ldo, T - q0w, lane);
+  if (q < T && h == 0) LSE[((long)b * Hq + hq) * T + q] = m * scale + __logf(l);
+  ATT_STAMP();  // stores issued
+}
+
+// The same decomposition, ring, merge and arithmetic (bit-identical outputs) with the K/V-tile loop SOFTWARE-PIPELINED
+// inside the wave.  In attn_fwd_kernel a tile is one dependent chain -- K fragments -> 8 MFMAs -> maxima -> 16 v_exp ->
+// bf16 P -> 8 MFMAs -- of ~2.1 k cycles for 512 cycles of matrix work, and on the heavy tile's SIMDs nothing else runs
+// beside it (round-2 stamps, profiles/r02_attn_fwd_stamps.txt: 2.9 k cycles per tile with the DMA issue and the barrier).
+// Here iteration i issues S^T(i+1) = K(i+1) Q^T FIRST and runs tile i's exponentials, row sums and bf16 conversion while the
+// matrix pipe works on it, then issues O^T += V(i)^T P(i)^T and computes tile i+1's mask and row maxima beside those:
+// both matrix products of an iteration have vector work of ANOTHER tile next to them.  The running-maximum update and
+// the (rare) rescale of O^T sit at the top of the iteration, before anything is issued.  Tile i+1 has to be in LDS one
+// iteration earlier than before, so the four-stage ring keeps two tiles in flight instead of three.
+__global__ __launch_bounds__(512) void attn_fwd_pipe_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ Kp,
+                                                            const bf16* __restrict__ Vp, bf16* __restrict__ O,
+                                                            float* __restrict__ LSE, const int* __restrict__ kv_len,
+                                                            long ldq, long ldk, long ldv, long ldo, int T, int Hq, int Hkv,
+                                                            float scale SD_ATT_STAMP_PARAM) {
+  __shared__ __attribute__((aligned(16))) char smem[8 * TILE];  // ring of 4 stages x (K,V)
+  const int lane = lane_id(), w8 = wave_id_uniform();
+  const int n64 = (T + 63) / 64;
+  const AttnWg wg = attn_wg((int)blockIdx.x, (n64 + 1) / 2, Hq / Hkv, Hkv, (int)gridDim.x / (((n64 + 1) / 2) * Hq));
+#ifdef SD_STAMPS
+  const bool stamping = stamps && wg.pair == 0 && wg.member_head == 0 && wg.hkv == 0 && wg.b == 0;
+  int sidx = 0;
+#endif
+  ATT_STAMP();  // 0: kernel entry
+  const int grp = w8 >> 2, rb = w8 & 1, half = (w8 >> 1) & 1;
+  const int w = grp * 2 + rb;
+  const int tA = n64 - 1 - wg.pair, tB = wg.pair;
+  const bool active = grp == 0 || tB != tA;
+  const int hkv = wg.hkv, b = wg.b;
+  const int hq = hkv * (Hq / Hkv) + wg.member_head;
+  const int q0w = (grp == 0 ? tA : tB) * 64 + 32 * rb;
+  const int r = lane & 31, h = lane >> 5;
+  const long tok0 = (long)b * T;
+  const bf16* qb = Q + tok0 * ldq + hq * D;
+  const bf16* kb = Kp + tok0 * ldk + hkv * D;
+  const bf16* vb = Vp + tok0 * ldv + hkv * D;
+  const int kv_hi = min(tA * 64 + 64, T);
+  const int nkv = (kv_hi + 63) / 64;
+  TileDma<2> kd, vd;
+  kd.init(kb, ldk, T, w8, lane);
+  vd.init(vb, ldv, T, w8, lane);
+  kd.issue(0, smem, w8);
+  vd.issue(0, smem + TILE, w8);
+  const int q = q0w + r;
+  const int qc = q < T ? q : T - 1;
+  bf16x8 qf[8];
+#pragma unroll
+  for (int st = 0; st < 8; ++st) qf[st] = *(const bf16x8*)(qb + (long)qc * ldq + 16 * st + 8 * h);
+  const int klen = kv_len ? max(1, min(kv_len[b], T)) : T;
+  const int lim = min(q, klen - 1);
+
+  f32x16 o[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[db][e] = 0.f;
+  float m = NEG, l = 0.f;
+  const float c = scale * LOG2E;
+  // tiles a wave computes: 0 .. nvis-1 (its keys of tile i start at 64 i + 32 half; at or below its rows' diagonal)
+  int nvis = 0;
+  if (active) {
+    const int last = (q0w + 31 - 32 * half) >> 6;  // floor; negative when even tile 0 is above the diagonal
+    nvis = (q0w + 31 - 32 * half) < 0 ? 0 : min(last + 1, (kv_hi - 32 * half + 63) >> 6);
+  }
+  // LDS offsets inside a tile.  The swizzle is an XOR on the 16-byte chunk index, so the eight K fragments of a lane are
+  // ONE offset XOR (st << 5), and the transposed V reads of a 16-key step are two offsets XOR (db << 6): 5 registers
+  // live across the loop instead of 24.
+  unsigned kf0, vf0[2][2];
+  {
+    const int row = 32 * half + (lane & 31);
+    kf0 = (unsigned)(row * 256 + (((lane >> 5) ^ f_swz(row)) << 4));
+    const int gi = lane >> 4, i16 = lane & 15, q4 = i16 >> 2, pp = i16 & 3;
+    const int chl = (gi & 1) * 2 + (pp >> 1);
+#pragma unroll
+    for (int ss = 0; ss < 2; ++ss) {
+      const int rA = 32 * half + 16 * ss + 4 * (gi >> 1) + q4, rB = rA + 8;
+      vf0[ss][0] = (unsigned)(8 * (pp & 1) + rA * 256 + ((chl ^ f_swz(rA)) << 4));
+      vf0[ss][1] = (unsigned)(8 * (pp & 1) + rB * 256 + ((chl ^ f_swz(rB)) << 4));
+    }
+  }
+  const unsigned smem_a = lds_addr(smem);
+  // S^T of one tile (this wave's 32 keys x its 32 rows): eight chained MFMAs on K fragments read from `stage`
+  auto s_tile = [&](int stage, f32x16& s) __attribute__((always_inline)) {
+    const char* ks = smem + stage * 2 * TILE;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) s[e] = 0.f;
+#pragma unroll
+    for (int st = 0; st < 8; ++st) s = mfma32(*(const bf16x8*)(ks + (kf0 ^ (unsigned)(st << 5))), qf[st], s);
+  };
+  // causal / padding mask (diagonal tiles only, behind a scalar branch) and the row maxima of a fresh S^T tile
+  auto mask_max = [&](int t, f32x16& s) __attribute__((always_inline)) -> float {
+    const int kv0 = t * 64 + 32 * half;
+    const bool need_mask = __builtin_amdgcn_readfirstlane((int)((kv0 + 31 > q0w) || (kv0 + 31 >= klen))) != 0;
+    if (need_mask) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) s[e] = (kv0 + acc_row(e, h)) > lim ? NEG : s[e];
+    }
+    float mx = fmaxf(fmaxf(s[0], s[1]), s[2]);
+#pragma unroll
+    for (int e = 3; e < 15; e += 2) mx = fmaxf(fmaxf(mx, s[e]), s[e + 1]);
+    mx = fmaxf(mx, s[15]);
+    return halves_max(mx);
+  };
+
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // Q fragments and my share of tile 0
+  // hipcc does not see that wait: without a use of the Q registers HERE it would wait for their loads at their first
+  // use inside the loop, with vmcnt(7..0) -- which by then drains the K/V tiles in flight
+#pragma unroll
+  for (int st = 0; st < 8; ++st) {
+    u32x4 t4 = __builtin_bit_cast(u32x4, qf[st]);
+    asm volatile("" : "+v"(t4));
+    qf[st] = __builtin_bit_cast(bf16x8, t4);
+  }
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  for (int t = 1; t <= 2; ++t)
+    if (t < nkv) {
+      char* nx = smem + (t & 3) * 2 * TILE;
+      kd.issue(t * 64, nx, w8);
+      vd.issue(t * 64, nx + TILE, w8);
+    }
+  f32x16 sc, sn;
+  float mx = NEG;
+  if (nvis > 0) {
+    s_tile(0, sc);
+    mx = mask_max(0, sc);
+  }
+  ATT_STAMP();  // 1: prologue done (tile 0 landed, S^T(0) issued)
+  for (int i = 0; i < nkv; ++i) {
+    // tile i+1 (whose K fragments this iteration reads) has landed; tile i+2 (4 loads of mine) may still be in flight
+    if (i + 2 < nkv) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ATT_STAMP();  // 2+4i: my loads of tile i+1 landed
+    __builtin_amdgcn_s_barrier();  // everybody's share of tile i+1 is there; everybody is done with tile i-1
+    asm volatile("" ::: "memory");
+    ATT_STAMP();  // 3+4i: barrier passed
+    const bool comp = i < nvis;  // wave-uniform
+    // All LDS reads of the iteration go out first, as asm (hipcc keeps only two K fragments in flight and then paces
+    // the S^T chain by the LDS latency: ~100 cycles per MFMA instead of 32): the 8 K fragments of tile i+1, then the
+    // transposed V reads of tile i's keys 0-15 of this wave; keys 16-31 follow once the K fragments are back (the
+    // LDS counter holds 15).  ONE code path: S^T(i+1) is also issued after the wave's last tile (on whatever the next
+    // stage holds; the result is dropped) -- a second path without it made hipcc copy the 64 O^T registers around the
+    // join every iteration.
+    const unsigned ksa = smem_a + ((i + 1) & 3) * 2 * TILE + kf0;
+    const unsigned vsa = smem_a + (i & 3) * 2 * TILE + TILE;
+    const unsigned va[2][2] = {{vsa + vf0[0][0], vsa + vf0[0][1]}, {vsa + vf0[1][0], vsa + vf0[1][1]}};
+    u32x4 kf[8];
+    sd_u64 rv0[8], rv1[8];
+    if (comp) {
+#pragma unroll
+      for (int st = 0; st < 8; ++st) asm volatile("ds_read_b128 %0, %1" : "=&v"(kf[st]) : "v"(ksa ^ (unsigned)(st << 5)));
+#pragma unroll
+      for (int db = 0; db < 4; ++db) lds_tr16_pair_asm(rv0[2 * db], rv0[2 * db + 1], va[0][0] ^ (unsigned)(db << 6), va[0][1] ^ (unsigned)(db << 6));
+    }
+    // the next tile's DMA goes out while those reads are in flight (~80 cycles of issue per piece)
+    if (i + 3 < nkv) {
+      char* nx = smem + ((i + 3) & 3) * 2 * TILE;
+      kd.issue((i + 3) * 64, nx, w8);
+      vd.issue((i + 3) * 64, nx + TILE, w8);
+    }
+    ATT_STAMP();  // 4+4i: reads and tile i+3 issued
+    if (!comp) {
+      ATT_STAMP();
+      continue;
+    }
+    const float mn = fmaxf(m, mx);
+    const float alpha = __builtin_amdgcn_exp2f((m - mn) * c);
+    m = mn;
+    const float mnc = -mn * c;
+    if (__any(alpha != 1.f)) {  // the running maximum moved for some row of this wave
+#pragma unroll
+      for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[db][e] *= alpha;
+    }
+    asm volatile("s_waitcnt lgkmcnt(8)"
+                 : "+v"(kf[0]), "+v"(kf[1]), "+v"(kf[2]), "+v"(kf[3]), "+v"(kf[4]), "+v"(kf[5]), "+v"(kf[6]), "+v"(kf[7]));
+#pragma unroll
+    for (int db = 0; db < 4; ++db) lds_tr16_pair_asm(rv1[2 * db], rv1[2 * db + 1], va[1][0] ^ (unsigned)(db << 6), va[1][1] ^ (unsigned)(db << 6));
+#pragma unroll
+    for (int e = 0; e < 16; ++e) sn[e] = 0.f;
+    // every MFMA of the S^T(i+1) chain with its share of tile i's vector work behind it, fenced: two exponentials
+    // (16 of the gap's 32 cycles), their two multiply-adds and two row-sum adds
+    float rs = 0.f;
+#pragma unroll
+    for (int st = 0; st < 8; ++st) {
+      sn = mfma32(__builtin_bit_cast(bf16x8, kf[st]), qf[st], sn);
+#pragma unroll
+      for (int e = 2 * st; e < 2 * st + 2; ++e) {
+        const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[e], c, mnc));
+        sc[e] = p;
+        rs += p;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    l = l * alpha + rs;
+    const bf16x8 p0 = acc_frag(sc, 0), p1 = acc_frag(sc, 1);
+    asm volatile("s_waitcnt lgkmcnt(8)"
+                 : "+v"(rv0[0]), "+v"(rv0[1]), "+v"(rv0[2]), "+v"(rv0[3]), "+v"(rv0[4]), "+v"(rv0[5]), "+v"(rv0[6]), "+v"(rv0[7]));
+#pragma unroll
+    for (int db = 0; db < 4; ++db) o[db] = mfma32(cat8_u64(rv0[2 * db], rv0[2 * db + 1]), p0, o[db]);
+    lds_tr_wait8(rv1);
+#pragma unroll
+    for (int db = 0; db < 4; ++db) o[db] = mfma32(cat8_u64(rv1[2 * db], rv1[2 * db + 1]), p1, o[db]);
+    mx = mask_max(i + 1, sn);
+    sc = sn;
+    ATT_STAMP();  // 5+4i: tile i computed (issue side)
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  ATT_STAMP();  // 2+4nkv: loop left, ring free
+  float* xo = (float*)smem + (long)w * 66 * 64;
+  if (half == 1) {
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) xo[(db * 16 + e) * 64 + lane] = o[db][e];
+    xo[64 * 64 + lane] = m;
+    xo[65 * 64 + lane] = l;
+  }
+  __syncthreads();
+  if (half == 1) return;
+  {
+    const float m1 = xo[64 * 64 + lane], l1 = xo[65 * 64 + lane];
+    const float mn = fmaxf(m, m1);
+    const float a0 = __builtin_amdgcn_exp2f((m - mn) * c), a1 = __builtin_amdgcn_exp2f((m1 - mn) * c);
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) o[db][e] = o[db][e] * a0 + xo[(db * 16 + e) * 64 + lane] * a1;
+    l = l * a0 + l1 * a1;
+    m = mn;
+  }
+  l += __shfl_xor(l, 32, 64);
+  const float inv = 1.f / l;
+  ATT_STAMP();  // merged
   if (!active) return;
   store_tile_rows((char*)xo, o, inv, O + (tok0 + q0w) * ldo + hq * D, ldo, T - q0w, lane);
   if (q < T && h == 0) LSE[((long)b * Hq + hq) * T + q] = m * scale + __logf(l);
@@ -728,6 +979,11 @@ extern "C" void sd_debug_attn_stamp_buffer(void* p) { g_attn_stamps = (unsigned 
 #define SD_ATT_STAMP_ARG
 #endif
 
+// bit 0: forward without the in-wave software pipeline (attn_fwd_kernel) at any T; bit 1: with it at any T (default:
+// from T = 1024); tests and A/B measurements
+static int g_attn_variant = 0;
+extern "C" void sd_attn_force_variant(int v) { g_attn_variant = v; }
+
 extern "C" int sd_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const int32_t* kv_len,
                            int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int B, int T, int Hq, int Hkv,
                            int head_dim, float scale, void* stream) {
@@ -735,7 +991,20 @@ extern "C" int sd_attn_fwd(const void* q, const void* k, const void* v, void* o,
   if (int e = check_common(B, T, Hq, Hkv, ldq, ldk, ldv, ldo)) return e;
   if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) & 15) return SD_ERR_ALIGN;
   SdProfScope prof(SD_K_ATTN_FWD, 2.0 * B * Hq * (double)T * T * D, (hipStream_t)stream);  // 2 products, causal half
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3((((T + 63) / 64 + 1) / 2) * Hq * B), dim3(512), 0, (hipStream_t)stream, (const bf16*)q,
+  static const bool classic_env = getenv("SD_ATTN_CLASSIC") && atoi(getenv("SD_ATTN_CLASSIC")) != 0;  // A/B measurements
+  const dim3 grid((((T + 63) / 64 + 1) / 2) * Hq * B);
+  // Measured (tests/bench_attn_pipe.py, MI355X, 16/8 heads): the pipelined kernel is 3-5 % faster from T = 1024 (21.8 vs
+  // 22.2 us at B=2, 32.9 vs 34.6 us at B=1 T=2048, 119 vs 123 us at B=4 T=2048) and ties or loses 0.1-0.5 us below
+  // (its prologue computes S^T(0) before the loop and needs tile 1 for the first iteration), so short streams keep the
+  // classic kernel.  bit 1 of the variant forces the pipelined one at any T (tests).
+  const bool pipe = (g_attn_variant & 2) || (!classic_env && !(g_attn_variant & 1) && T >= 1024);
+  if (pipe) {
+    hipLaunchKernelGGL(attn_fwd_pipe_kernel, grid, dim3(512), 0, (hipStream_t)stream, (const bf16*)q, (const bf16*)k,
+                       (const bf16*)v, (bf16*)o, lse, kv_len, ldq, ldk, ldv, ldo, T, Hq, Hkv, scale SD_ATT_STAMP_ARG);
+    SD_CHECK_LAUNCH();
+    return 0;
+  }
+  hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(512), 0, (hipStream_t)stream, (const bf16*)q,
                      (const bf16*)k, (const bf16*)v, (bf16*)o, lse, kv_len, ldq, ldk, ldv, ldo, T, Hq, Hkv, scale SD_ATT_STAMP_ARG);
   SD_CHECK_LAUNCH();
   return 0;

@@ -1,4 +1,4 @@
-"""GPU diagnostic (not a pytest): where attn_fwd_kernel's heaviest workgroup spends its cycles.  Needs the stamp build,
+"""GPU diagnostic (not a pytest): where the heaviest workgroup of attn_fwd_pipe_kernel / attn_fwd_kernel spends its cycles.  Needs the stamp build,
 made ON the GPU box (the library lives in /tmp):
     make -C speech_distill_amd/csrc stamps && SD_HIP_LIB=/tmp/sd_stamps/libsd_hip.so python tests/bench_attn_stamps.py
 Prints s_memtime deltas (100 MHz ticks -> ns) of waves 0 (heavy tile, keys 0-31), 2 (heavy, keys 32-63) and 4 (light)."""
@@ -21,7 +21,8 @@ def main():
     lib.sd_debug_attn_stamp_buffer.restype = None
     buf = torch.zeros(8 * 256, dtype=torch.int64, device=dev)
     Hq, Hkv = 16, 8
-    for B, T in ((4, 512), (1, 2048)):
+    for variant, B, T in ((2, 4, 512), (1, 4, 512), (2, 1, 2048), (1, 1, 2048)):
+        lib.sd_attn_force_variant(variant)
         M = B * T
         qkv = torch.randn(M, (Hq + 2 * Hkv) * 128, device=dev).bfloat16()
         q, k, v = qkv[:, :Hq * 128], qkv[:, Hq * 128:(Hq + Hkv) * 128], qkv[:, (Hq + Hkv) * 128:]
@@ -36,7 +37,7 @@ def main():
         st = buf.cpu().view(8, 256).tolist()
         nkv = T // 64
         t0 = min(st[w][0] for w in range(8))
-        print(f"== B={B} T={T}: nkv={nkv}; shader cycles since the first wave's entry")
+        print(f"== {'classic' if variant == 1 else 'pipelined'} kernel, B={B} T={T}: nkv={nkv}; shader cycles since the first wave's entry")
         for w in (0, 2, 4):
             r = [x - t0 for x in st[w]]
             print(f" wave {w}: entry {r[0]}  prologue issued {r[1]}")

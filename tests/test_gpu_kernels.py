@@ -619,6 +619,36 @@ def test_attention_fwd_bwd(ops, O, B, T, Hq, Hkv, pad):
     check_close(f"attn_bwd_dv_B{B}T{T}p{int(pad)}", dv, vr.grad, 2e-2, 6e-3)
 
 
+@pytest.mark.parametrize("B,T,Hq,Hkv,pad", [(4, 512, 16, 8, False), (1, 2048, 4, 2, False), (2, 330, 4, 2, True),
+                                            (3, 72, 8, 8, True), (1, 40, 2, 1, False), (2, 576, 2, 1, True),
+                                            (8, 64, 2, 1, False), (2, 1000, 4, 4, True)])
+def test_attention_fwd_pipelined_equals_classic(ops, B, T, Hq, Hkv, pad):
+    """attn_fwd_pipe_kernel (S^T of tile i+1 issued before tile i's softmax; the default) keeps the arithmetic and its
+    order, so output and log-sum-exp equal attn_fwd_kernel's bit for bit (one to nine K/V tiles per stream, odd pair
+    counts, ragged last tile, right padding, the XCD-aware and the natural workgroup numbering)."""
+    from speech_distill_amd._lib import load_lib
+    g = torch.Generator().manual_seed(7 * T + Hq)
+    M = B * T
+    qkv = bf(torch.randn(M, (Hq + 2 * Hkv) * 128, generator=g) * 1.7).to(dev())
+    q, k, v = qkv[:, :Hq * 128], qkv[:, Hq * 128:(Hq + Hkv) * 128], qkv[:, (Hq + Hkv) * 128:]
+    kv_len = None
+    if pad:
+        kv_len = torch.tensor([max(1, T - 5 - 37 * b) for b in range(B)], dtype=torch.int32, device=dev())
+    lib = load_lib()
+    outs = []
+    try:
+        for variant in (2, 1):
+            lib.sd_attn_force_variant(variant)
+            o, lse = ops.attn_fwd(q, k, v, B, T, Hq, Hkv, kv_len)
+            torch.cuda.synchronize()
+            outs.append((o.clone(), lse.clone()))
+    finally:
+        lib.sd_attn_force_variant(0)
+    assert torch.isfinite(outs[0][0].float()).all()
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert torch.equal(outs[0][1], outs[1][1])
+
+
 # ------------------------------------------------------------------------------------------ top-K
 def test_topk_golden_fp32(ops):
     """G2: the reference's own train.py:80-91 outputs (fp32 logits, no ties) must be reproduced bit for bit
