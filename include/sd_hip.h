@@ -85,7 +85,7 @@ int sd_gemm_grouped_tn(const sd_gemm_problem* probs, int n, int K, int accumulat
 /* The SAME forward projection of two independent models (student + frozen teacher in lockstep, train.py:54 and
  * train.py:60-69 on one stream; or any two NT GEMMs) as ONE persistent launch: C_p [M,N] = A_p [M,K] . B_p [N,K]^T,
  * p < n <= 2, K % 64 == 0.  nsplit > 1 cuts K into that many slices, each writing an fp32 slab [nsplit][M][N] into
- * `slabs` (summed by the consumer, sd_rmsnorm_fwd_pair) instead of C.  swiglu != 0: B = [gate rows | up rows] [2I,K],
+ * `slabs` (summed by the consumer, sd_rmsnorm_fwd_slabs) instead of C.  swiglu != 0: B = [gate rows | up rows] [2I,K],
  * N = 2I, act [M,I] = silu(gate) * up -> out2, gate|up -> C when C != NULL (HF:81-83), nsplit must be 1. */
 typedef struct {
   const void* A;
