@@ -5,7 +5,6 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import speech_distill_amd as sda
 from speech_distill_amd import ops
-from oracle.qwen3 import STUDENT_06B, TEACHER_17B, flops_per_token  # FLOP-count constants only
 
 dev = torch.device("cuda:0")
 
@@ -40,7 +39,7 @@ def c5():
 
 
 dt = timeit(c5)
-f = flops_per_token(TEACHER_17B, 512)
+f = sda.Qwen3Dims.teacher_17b().flops_per_token(512)
 print(json.dumps({"config": "C5 teacher-only B=64 T=512 + top-100", "tokens_per_s": 64 * 512 / dt, "ms": dt * 1e3,
                   "mfma_frac": 64 * 512 / dt * f / 2.5e15}), flush=True)
 del ids
@@ -68,7 +67,7 @@ def c4():  # the sequence of DistillationTrainer.compute_loss on a training step
 
 
 dt = timeit(c4, n=3, w=1)
-f = 3 * flops_per_token(STUDENT_06B, T) + flops_per_token(TEACHER_17B, T)
+f = 3 * sda.Qwen3Dims.student_06b().flops_per_token(T) + sda.Qwen3Dims.teacher_17b().flops_per_token(T)
 print(json.dumps({"config": "C4-shaped step B=4 T=2048 (1 GPU), head on the loss rows, teacher beside the student", "tokens_per_s": B * T / dt, "ms": dt * 1e3,
                   "mfma_frac": B * T / dt * f / 2.5e15}), flush=True)
 
