@@ -124,6 +124,10 @@ def main():
                     help="MEASUREMENT ONLY (not the reported configuration): select the loss rows once instead of every "
                          "step -- an upper bound on what the per-step host read of the row count costs")
     ap.add_argument("--no-overlap", action="store_true", help="single stream everywhere (clean per-kernel profiles)")
+    ap.add_argument("--experiment-cu-hog", type=int, default=0, metavar="N",
+                    help="MEASUREMENT ONLY (not the reported configuration): N idle workgroups (256 threads, 128 registers "
+                         "per lane: a communication kernel's footprint) hold a CU slot each during every backward, on a "
+                         "stream of their own -- how the backward reacts when RCCL's kernels take CUs (tests/csrc/cu_hog.hip)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -183,6 +187,13 @@ def main():
         e.record()
         phase_ev.append(e)
 
+    hog = None
+    if args.experiment_cu_hog > 0:
+        import ctypes
+        hog_lib = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "libcu_hog.so"))
+        hog_lib.cu_hog.restype, hog_lib.cu_hog.argtypes = ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+        hog = (hog_lib, torch.cuda.Stream(device=dev))
+
     def step(overlap=True):
         # the same sequence as speech_distill_amd.trainer.DistillationTrainer.compute_loss on a training step
         student.zero_grad()
@@ -219,6 +230,10 @@ def main():
                 side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(side):
                     pending.append(teacher_topk(rows))
+        if hog is not None:  # EXPERIMENT (also in the one-stream per-kernel pass: which kernels pay): from here for 8.5 ms (the backward takes ~8.8), then they leave
+            hog[1].wait_stream(torch.cuda.current_stream())
+            rc = hog[0].cu_hog(args.experiment_cu_hog, 8500, hog[1].cuda_stream)
+            assert rc == 0, rc
         total.backward()                                                                    # HF trainer.py:1961
         mark()
         return total, task, distill, teach
@@ -422,10 +437,11 @@ def main():
             del opt
         except Exception as e:
             res["optimizer_step_ms"] = repr(e)
-        if args.experiment_pipeline or args.experiment_cached_rows:
+        if args.experiment_pipeline or args.experiment_cached_rows or args.experiment_cu_hog:
             res["experiment"] = "NOT the reported configuration: " + " ".join(
                 f for f, on in (("--experiment-pipeline", args.experiment_pipeline),
-                                ("--experiment-cached-rows", args.experiment_cached_rows)) if on)
+                                ("--experiment-cached-rows", args.experiment_cached_rows),
+                                (f"--experiment-cu-hog {args.experiment_cu_hog}", args.experiment_cu_hog)) if on)
         if world == 1 and not args.no_cpu_baseline:
             try:
                 cb, sw, tw, cbatch, cout = cpu_baseline(args.cpu_sample_tokens, min(os.cpu_count() or 1, 16))

@@ -97,7 +97,10 @@ typedef struct {
   int32_t M, N, K, nsplit;
 } sd_gemm_nt_problem;
 int sd_gemm_grouped_nt(const sd_gemm_nt_problem* probs, int n, int swiglu, void* stream);
-/* measurements only (tests/bench_partition.py): cap the workgroups of every later sd_gemm_grouped_nt launch (0 = one per CU) */
+/* cap the workgroups of every later persistent grouped launch (sd_gemm_grouped_nt: measurements, tests/bench_partition.py) and
+ * of the backward's persistent weight-gradient launches (sd_gemm_grouped_tn, the TN form of sd_gemm_bf16); 0 = one per CU.
+ * The environment variable SD_GEMM_CU_BUDGET sets the same for the weight-gradient launches of a multi-GPU run, where
+ * RCCL's kernels hold CUs beside the backward. */
 void sd_debug_cu_budget(int cus);
 /* backward twin: d(gate|up) [M,2I] = SwiGLU'(gate_up) applied to d(act) = dy [M,H] . W_down [H,I], in the epilogue of
  * that GEMM (d(act) is never stored); equals sd_gemm_bf16 (NN) + sd_swiglu_bwd bit for bit. */

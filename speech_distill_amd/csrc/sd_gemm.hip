@@ -2015,7 +2015,15 @@ void* g_stamp_buffer = nullptr;  // diagnostic build: device buffer for the phas
 bool g_no_fast_stage = false;  // tests / A-B measurements: force the checked staging path
 bool g_force_p1 = false;       // tests / A-B measurements: gemm_p1_kernel where gemm_pstag_kernel would run (nst | 0x200)
 bool g_force_p256_unpaired = false;  // tests / A-B measurements: the 32-deep-stage form of gemm_p256_kernel (nst | 0x400)
-int g_cu_budget = 0;           // EXPERIMENT: workgroups a persistent grouped launch may use (0 = every CU)
+int g_cu_budget = 0;           // workgroups a persistent grouped / weight-gradient launch may use (0 = every CU): sd_debug_cu_budget
+// SD_GEMM_CU_BUDGET (multi-GPU runs): the persistent kernels of the BACKWARD (grouped weight gradients, lm_head weight
+// gradient) take one workgroup per CU for their whole duration; when RCCL's reduction kernels hold c CUs meanwhile, c
+// workgroups start only after others have finished and the launch takes up to twice as long (measured with
+// bench.py --experiment-cu-hog 16: +22 % / +70 %).  A budget of 256 - c keeps every workgroup resident from the start.
+static int cu_budget() {
+  static const int env = getenv("SD_GEMM_CU_BUDGET") ? atoi(getenv("SD_GEMM_CU_BUDGET")) : 0;
+  return g_cu_budget > 0 ? g_cu_budget : env;
+}
 thread_local bool g_skip_reduce = false;  // set by sd_gemm_bf16_splitk_partial around its dispatch
 
 template <int BM, int NST, bool TA, bool TB>
@@ -2096,7 +2104,10 @@ int launch(const void* A, const void* B, void* C, const void* R, float* slabs, i
       if (splits == 1 && tiles_m * tiles_n > persist_grid && persist_grid > 0) {                                       \
         SD_PROF_LABEL("gemm_pstag_kernel<4, %s, %s, %d>", TA ? "true" : "false", TB ? "true" : "false", EPI);          \
         SD_STAMP_ARGS();                                                                                               \
-        hipLaunchKernelGGL((gemm_pstag_kernel<4, TA, TB, EPI>), dim3(persist_grid), dim3(768), 0, st, (const bf16*)A,  \
+        /* weight gradients (TA): the backward's persistent launches honour the CU budget of a multi-GPU run */       \
+        const int pg = (TA && cu_budget() > 0 && (cu_budget() & ~7) > 0 && (cu_budget() & ~7) < persist_grid)          \
+                           ? (cu_budget() & ~7) : persist_grid;                                                        \
+        hipLaunchKernelGGL((gemm_pstag_kernel<4, TA, TB, EPI>), dim3(pg), dim3(768), 0, st, (const bf16*)A,            \
                            (const bf16*)B, (bf16*)C, (const bf16*)R, M, N, K, lda, ldb, ldc, ldr, tiles_m, tiles_n,    \
                            gm, SD_STAMP_EA);                                                                           \
         break;                                                                                                         \
@@ -2321,6 +2332,7 @@ extern "C" int sd_gemm_grouped_tn(const sd_gemm_problem* probs, int n, int K, in
     return SD_ERR_UNSUPPORTED;
   cus &= ~7;
   if (cus <= 0) return SD_ERR_UNSUPPORTED;
+  if (cu_budget() > 0 && (cu_budget() & ~7) < cus && (cu_budget() & ~7) > 0) cus = cu_budget() & ~7;
   SdProfScope prof(SD_K_GEMM_TN, flops, (hipStream_t)stream);
   SD_PROF_LABEL("gemm_pgroup_tn_kernel<%s>", accumulate ? "true" : "false");
   // A/B (tests/bench_grouped.py, MI355X): sharing the DMA issue with the compute waves is 2-4 % SLOWER here (73.5-74.6 vs

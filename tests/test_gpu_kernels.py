@@ -401,6 +401,42 @@ def test_gemm_grouped_tn_equals_separate_gemms(ops, K):
         assert torch.equal(acc[i], want[i]), (i, float((acc[i].float() - want[i].float()).abs().max()))
 
 
+@pytest.mark.parametrize("budget", [240, 64])
+def test_persistent_weight_gradient_kernels_under_a_cu_budget(ops, budget, monkeypatch):
+    """sd_debug_cu_budget (SD_GEMM_CU_BUDGET in a multi-GPU run): the backward's persistent launches -- the grouped
+    weight gradients and the lm_head-class TN GEMM -- on fewer workgroups than CUs give the same results bit for bit
+    (a workgroup just walks more tiles), also while idle workgroups hold CU slots beside them (tests/csrc/cu_hog.hip)."""
+    import ctypes
+    import os
+    g = torch.Generator().manual_seed(budget)
+    K = 512
+    shapes = [(4096, 1024), (1024, 2048), (6144, 1024), (1024, 3072)]
+    pairs = [(to_dev(bf(torch.randn(K, m, generator=g))), to_dev(bf(torch.randn(K, n, generator=g)))) for m, n in shapes]
+    dl, xn = to_dev(bf(torch.randn(300, 40000, generator=g))), to_dev(bf(torch.randn(300, 1024, generator=g)))
+    ref = ops.gemm_grouped_tn(pairs)
+    ref_head = ops.gemm(dl, xn, True, True)  # [40000, 1024]: 1256 tiles of 256 x 128, the persistent TN kernel
+    lib = ops.load_lib()
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libcu_hog.so")
+    hog = None
+    if os.path.exists(path):
+        hog = ctypes.CDLL(path)
+        hog.cu_hog.restype, hog.cu_hog.argtypes = ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    side = torch.cuda.Stream()
+    lib.sd_debug_cu_budget(budget)
+    try:
+        for it in range(3):
+            if hog is not None and it:
+                assert hog.cu_hog(16, 500, side.cuda_stream) == 0
+            got = ops.gemm_grouped_tn(pairs)
+            got_head = ops.gemm(dl, xn, True, True)
+            torch.cuda.synchronize()
+            for i in range(4):
+                assert torch.equal(got[i], ref[i]), (it, i)
+            assert torch.equal(got_head, ref_head), it
+    finally:
+        lib.sd_debug_cu_budget(0)
+
+
 @pytest.mark.parametrize("M,T,Hq,H", [(2048, 512, 16, 1024), (300, 100, 2, 256)])
 def test_gemm_odx_delta_epilogue(ops, M, T, Hq, H):
     """o-projection dX with delta = rowsum(dO * O) per (token, head) in the epilogue: d_ao bit-identical to the plain NN
