@@ -25,6 +25,12 @@ constexpr int KMAX = 1024;
 
 template <typename T> struct Ld8;
 template <> struct Ld8<bf16> {
+  typedef bf16x8 Raw;  // 8 elements as loaded (prefetched chunks wait in registers in this form)
+  static SD_DEV Raw raw(const bf16* p) { return *(const bf16x8*)p; }
+  static SD_DEV void cvt(const Raw& v, float* f) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = (float)v[e];
+  }
   static SD_DEV void load(const bf16* p, float* f) {
     bf16x8 v = *(const bf16x8*)p;
 #pragma unroll
@@ -38,6 +44,11 @@ template <> struct Ld8<bf16> {
   }
 };
 template <> struct Ld8<float> {
+  struct Raw { f32x4 a, b; };
+  static SD_DEV Raw raw(const float* p) { return Raw{*(const f32x4*)p, *(const f32x4*)(p + 4)}; }
+  static SD_DEV void cvt(const Raw& v, float* f) {
+    f[0] = v.a[0]; f[1] = v.a[1]; f[2] = v.a[2]; f[3] = v.a[3]; f[4] = v.b[0]; f[5] = v.b[1]; f[6] = v.b[2]; f[7] = v.b[3];
+  }
   static SD_DEV void load(const float* p, float* f) {
     f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
     f[0] = a[0]; f[1] = a[1]; f[2] = a[2]; f[3] = a[3]; f[4] = b[0]; f[5] = b[1]; f[6] = b[2]; f[7] = b[3];
@@ -69,20 +80,23 @@ struct RowStats {  // 8 floats per row
 };
 
 // merge (m, s) online-softmax partials across the block; returns the block totals to all threads
+template <int NF>
 SD_DEV void block_merge(float& m, float& s1, float& sT, float invT, float* sc) {
-  const float M = block_max<NT>(m, sc);
+  const float M = block_max<NF>(m, sc);
   const float f1 = (m == -INFINITY) ? 0.f : __expf(m - M);
   const float fT = (m == -INFINITY) ? 0.f : __expf((m - M) * invT);
-  s1 = block_sum<NT>(s1 * f1, sc);
-  sT = block_sum<NT>(sT * fT, sc);
+  s1 = block_sum<NF>(s1 * f1, sc);
+  sT = block_sum<NF>(sT * fT, sc);
   m = M;
 }
 
 // T2: temperature == 2 (the reference's default, train.py:488-491).  Then exp(z) = exp(z / 2)^2, so the sum-exp at T = 1
 // comes from the T = 2 exponential by one multiplication: half the transcendentals of a kernel that is bound by them
 // (129 us = 3.8 TB/s before, with two v_exp_f32 per logit at a quarter of the vector rate).
-template <typename T, bool T2>
-__global__ __launch_bounds__(NT) void kd_fwd_kernel(const T* __restrict__ S, const T* __restrict__ Tl,
+// NF threads per row: 512 (four workgroups per CU, 128 chunks of a CU in flight) whenever the K teacher entries fit one
+// thread each, else 1024.  DENSE: teacher logits instead of top-K (its prefetch registers only exist in that variant).
+template <typename T, bool T2, int NF, bool DENSE>
+__global__ __launch_bounds__(NF) void kd_fwd_kernel(const T* __restrict__ S, const T* __restrict__ Tl,
                                                     const _Float16* __restrict__ topv, const int32_t* __restrict__ topi,
                                                     const int64_t* __restrict__ labels, const uint8_t* __restrict__ mask,
                                                     RowStats* __restrict__ stats, int rows, int Tlen, int V, int K,
@@ -102,58 +116,81 @@ __global__ __launch_bounds__(NT) void kd_fwd_kernel(const T* __restrict__ S, con
   float m = -INFINITY, s1 = 0.f, sT = 0.f;
   // ---- dense teacher: max, sum-exp at 1 and T, cross = sum exp((t-mt)/T) (t - s)
   float mt = -INFINITY, t1 = 0.f, tT = 0.f, cross = 0.f;
-  const T* tl = Tl ? Tl + (long)row * V : nullptr;
-  for (int c = threadIdx.x * 8; c < V; c += NT * 8) {
-    float f[8];
-    Ld8<T>::load(s + c, f);
-    float cm = f[0];
+  const T* tl = DENSE ? Tl + (long)row * V : nullptr;
+  // The row is streamed with PF chunks per thread in flight: with one (load, wait, compute) per trip the 32 waves of a CU
+  // keep 32 KB outstanding, which at ~2 us of loaded HBM latency is 4 TB/s whatever the kernel does (measured 3.9-4.1).
+  // Each thread still sees its chunks in the same order: the sums are bit for bit the ones of the plain loop.
+  constexpr int PF = 4;
+  typedef typename Ld8<T>::Raw Raw;
+  const int stride = NF * 8;
+  Raw sbuf[PF], tbuf[DENSE ? PF : 1];
+  // every load is UNCONDITIONAL (a chunk past the end re-reads the row's last one and is never used): with loads behind
+  // branches hipcc's wait insertion falls back to vmcnt(0) at every use and drains the chunks in flight
+  const int clast = ((V - 1) >> 3) << 3;  // start of the row's last chunk
 #pragma unroll
-    for (int e = 1; e < 8; ++e) cm = fmaxf(cm, f[e]);
-    if (cm > m) {
-      const float rT = __expf((m - cm) * invT), r1 = T2 ? rT * rT : __expf(m - cm);
-      s1 *= r1; sT *= rT; m = cm;
-    }
-    // exp((f - m) / T) = exp2(f * kT - m * kT): one fused multiply-add per exponential argument
-    const float mkT = -m * kT, mk1 = -m * k1;
+  for (int j = 0; j < PF; ++j) {
+    const int cj = min((int)threadIdx.x * 8 + j * stride, clast);
+    sbuf[j] = Ld8<T>::raw(s + cj);
+    if constexpr (DENSE) tbuf[j] = Ld8<T>::raw(tl + cj);
+  }
+  for (int c0 = threadIdx.x * 8; c0 < V; c0 += PF * stride) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float q = __builtin_amdgcn_exp2f(__builtin_fmaf(f[e], kT, mkT));
-      sT += q;
-      s1 += T2 ? q * q : __builtin_amdgcn_exp2f(__builtin_fmaf(f[e], k1, mk1));
-    }
-    if (tl) {
-      float g[8];
-      Ld8<T>::load(tl + c, g);
-      float tm = g[0];
+    for (int j = 0; j < PF; ++j) {
+      const int c = c0 + j * stride;
+      float f[8], g[8];
+      Ld8<T>::cvt(sbuf[j], f);
+      if constexpr (DENSE) Ld8<T>::cvt(tbuf[j], g);
+      const int cn = min(c + PF * stride, clast);  // refill the slot before the arithmetic
+      sbuf[j] = Ld8<T>::raw(s + cn);
+      if constexpr (DENSE) tbuf[j] = Ld8<T>::raw(tl + cn);
+      if (c >= V) continue;
+      float cm = f[0];
 #pragma unroll
-      for (int e = 1; e < 8; ++e) tm = fmaxf(tm, g[e]);
-      if (tm > mt) {
-        const float rT = __expf((mt - tm) * invT), r1 = T2 ? rT * rT : __expf(mt - tm);
-        t1 *= r1; tT *= rT; cross *= rT; mt = tm;
+      for (int e = 1; e < 8; ++e) cm = fmaxf(cm, f[e]);
+      if (cm > m) {
+        const float rT = __expf((m - cm) * invT), r1 = T2 ? rT * rT : __expf(m - cm);
+        s1 *= r1; sT *= rT; m = cm;
       }
-      const float tkT = -mt * kT, tk1 = -mt * k1;
+      // exp((f - m) / T) = exp2(f * kT - m * kT): one fused multiply-add per exponential argument
+      const float mkT = -m * kT, mk1 = -m * k1;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const float w = __builtin_amdgcn_exp2f(__builtin_fmaf(g[e], kT, tkT));
-        t1 += T2 ? w * w : __builtin_amdgcn_exp2f(__builtin_fmaf(g[e], k1, tk1));
-        tT += w;
-        cross += w * (g[e] - f[e]);
+        const float q = __builtin_amdgcn_exp2f(__builtin_fmaf(f[e], kT, mkT));
+        sT += q;
+        s1 += T2 ? q * q : __builtin_amdgcn_exp2f(__builtin_fmaf(f[e], k1, mk1));
+      }
+      if constexpr (DENSE) {
+        float tm = g[0];
+#pragma unroll
+        for (int e = 1; e < 8; ++e) tm = fmaxf(tm, g[e]);
+        if (tm > mt) {
+          const float rT = __expf((mt - tm) * invT), r1 = T2 ? rT * rT : __expf(mt - tm);
+          t1 *= r1; tT *= rT; cross *= rT; mt = tm;
+        }
+        const float tkT = -mt * kT, tk1 = -mt * k1;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float w = __builtin_amdgcn_exp2f(__builtin_fmaf(g[e], kT, tkT));
+          t1 += T2 ? w * w : __builtin_amdgcn_exp2f(__builtin_fmaf(g[e], k1, tk1));
+          tT += w;
+          cross += w * (g[e] - f[e]);
+        }
       }
     }
   }
-  block_merge(m, s1, sT, invT, sc);
+  block_merge<NF>(m, s1, sT, invT, sc);
   const float lse1 = m + __logf(s1);
   const float lseT = m * invT + __logf(sT);
   const float sy = (float)s[y];
   const float task = lse1 - sy;
   float distill = 0.f, teacher = 0.f, hits = 0.f, t_lseT = 0.f;
-  if (tl) {
-    const float MT = block_max<NT>(mt, sc);
+  if constexpr (DENSE) {
+    const float MT = block_max<NF>(mt, sc);
     const float f1 = (mt == -INFINITY) ? 0.f : __expf(mt - MT);
     const float fT = (mt == -INFINITY) ? 0.f : __expf((mt - MT) * invT);
-    t1 = block_sum<NT>(t1 * f1, sc);
-    tT = block_sum<NT>(tT * fT, sc);
-    cross = block_sum<NT>(cross * fT, sc);
+    t1 = block_sum<NF>(t1 * f1, sc);
+    tT = block_sum<NF>(tT * fT, sc);
+    cross = block_sum<NF>(cross * fT, sc);
     t_lseT = MT * invT + __logf(tT);
     // sum_v q (log q - log p) = (1/T) sum_v q (t - s) - t_lseT + lseT      (sum_v q = 1)
     distill = cross / tT * invT - t_lseT + lseT;
@@ -165,9 +202,9 @@ __global__ __launch_bounds__(NT) void kd_fwd_kernel(const T* __restrict__ S, con
     const bool act = threadIdx.x < K;
     const float v = act ? (float)topv[kb + threadIdx.x] : -INFINITY;
     const int idx = act ? topi[kb + threadIdx.x] : 0;
-    const float mv = block_max<NT>(v, sc);
+    const float mv = block_max<NF>(v, sc);
     const float ev = act ? __expf((v - mv) * invT) : 0.f;
-    const float sv = block_sum<NT>(ev, sc);
+    const float sv = block_sum<NF>(ev, sc);
     const float logq = (v - mv) * invT - __logf(sv);
     float term = 0.f, hv = 0.f, hc = 0.f;
     if (act) {
@@ -176,9 +213,9 @@ __global__ __launch_bounds__(NT) void kd_fwd_kernel(const T* __restrict__ S, con
       term = (ev / sv) * (logq - logp);
       if ((long)idx == y) { hv = v; hc = 1.f; }
     }
-    distill = block_sum<NT>(term, sc);
-    teacher = block_sum<NT>(hv, sc);   // sum of teacher log-probs at the label, over hits
-    hits = block_sum<NT>(hc, sc);
+    distill = block_sum<NF>(term, sc);
+    teacher = block_sum<NF>(hv, sc);   // sum of teacher log-probs at the label, over hits
+    hits = block_sum<NF>(hc, sc);
   }
   if (threadIdx.x == 0) stats[row] = RowStats{lse1, lseT, t_lseT, 1.f, task, distill, teacher, hits};
 }
@@ -292,14 +329,15 @@ int run_fwd(const void* S, const void* Tl, const void* topv, const void* topi, c
   const int rows = Tlen ? B * Tlen : B;  // Tlen == 0: B pre-selected rows
   SdProfScope prof(SD_K_LOSS_FWD, (double)rows * V * sizeof(T) * (Tl ? 2 : 1), st);
   SD_PROF_LABEL("kd_fwd_kernel<%s, %s>", sizeof(T) == 2 ? "__bf16" : "float", temperature == 2.0f ? "true" : "false");
-  if (temperature == 2.0f)
-    hipLaunchKernelGGL((kd_fwd_kernel<T, true>), dim3(rows), dim3(NT), 0, st, (const T*)S, (const T*)Tl,
-                       (const _Float16*)topv, (const int32_t*)topi, labels, mask, (RowStats*)stats, rows, Tlen, V, K,
-                       temperature);
-  else
-    hipLaunchKernelGGL((kd_fwd_kernel<T, false>), dim3(rows), dim3(NT), 0, st, (const T*)S, (const T*)Tl,
-                       (const _Float16*)topv, (const int32_t*)topi, labels, mask, (RowStats*)stats, rows, Tlen, V, K,
-                       temperature);
+#define SD_KD_FWD(T2_, NF_, DENSE_)                                                                                      \
+  hipLaunchKernelGGL((kd_fwd_kernel<T, T2_, NF_, DENSE_>), dim3(rows), dim3(NF_), 0, st, (const T*)S, (const T*)Tl,        \
+                     (const _Float16*)topv, (const int32_t*)topi, labels, mask, (RowStats*)stats, rows, Tlen, V, K,          \
+                     temperature)
+  const bool t2 = temperature == 2.0f;
+  if (Tl) { if (t2) SD_KD_FWD(true, 512, true); else SD_KD_FWD(false, 512, true); }
+  else if (K <= 512) { if (t2) SD_KD_FWD(true, 512, false); else SD_KD_FWD(false, 512, false); }
+  else { if (t2) SD_KD_FWD(true, 1024, false); else SD_KD_FWD(false, 1024, false); }
+#undef SD_KD_FWD
   SD_CHECK_LAUNCH();
   hipLaunchKernelGGL(kd_finalize_kernel, dim3(1), dim3(NT), 0, st, (const RowStats*)stats, out, rows, temperature, alpha,
                      Tl ? 1 : 0);

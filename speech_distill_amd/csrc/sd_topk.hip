@@ -25,6 +25,18 @@ SD_DEV float key2f(uint32_t k) {
   return __uint_as_float(u);
 }
 
+template <typename T> struct Raw8;
+template <> struct Raw8<bf16> { typedef bf16x8 R; };
+template <> struct Raw8<float> { struct R { f32x4 a, b; }; };
+SD_DEV bf16x8 raw8(const bf16* p) { return *(const bf16x8*)p; }
+SD_DEV Raw8<float>::R raw8(const float* p) { return Raw8<float>::R{*(const f32x4*)p, *(const f32x4*)(p + 4)}; }
+SD_DEV void cvt8(const bf16x8& v, float* f) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) f[e] = (float)v[e];
+}
+SD_DEV void cvt8(const Raw8<float>::R& v, float* f) {
+  f[0] = v.a[0]; f[1] = v.a[1]; f[2] = v.a[2]; f[3] = v.a[3]; f[4] = v.b[0]; f[5] = v.b[1]; f[6] = v.b[2]; f[7] = v.b[3];
+}
 template <typename T> SD_DEV void load8(const T* p, float* f);
 template <> SD_DEV void load8<bf16>(const bf16* p, float* f) {
   bf16x8 v = *(const bf16x8*)p;
@@ -125,13 +137,23 @@ __global__ __launch_bounds__(NT) void topk_kernel(const T* __restrict__ X, _Floa
   const bool keep_max = MAXCH > 0 && V <= MAXCH * NT * 8;
   float cmx[MAXCH > 0 ? MAXCH : 1];
   if (keep_max) {
+    // PF chunks per thread in flight (one load per trip leaves a CU's 32 waves with 32 KB outstanding: ~4 TB/s at the
+    // loaded HBM latency, whatever the arithmetic); the chunks are consumed in the same order
+    constexpr int PF = 4;
+    typename Raw8<T>::R buf[PF];
+    // every load is UNCONDITIONAL (a chunk past the end re-reads the row's last one and is not used): with loads behind
+    // branches hipcc's wait insertion falls back to vmcnt(0) at every use and drains the chunks in flight
+    const int clast = ((V - 1) >> 3) << 3;  // start of the row's last chunk
+#pragma unroll
+    for (int j = 0; j < PF; ++j) buf[j] = raw8(x + min((j * NT + (int)threadIdx.x) * 8, clast));
 #pragma unroll
     for (int i = 0; i < MAXCH; ++i) {
       const int c = (i * NT + (int)threadIdx.x) * 8;
       cmx[i] = -INFINITY;
+      float f[8];
+      cvt8(buf[i % PF], f);
+      if (i + PF < MAXCH) buf[i % PF] = raw8(x + min(((i + PF) * NT + (int)threadIdx.x) * 8, clast));
       if (c < V) {
-        float f[8];
-        load8<T>(x + c, f);
         float cm = f[0];
 #pragma unroll
         for (int e = 1; e < 8; ++e) cm = fmaxf(cm, f[e]);
