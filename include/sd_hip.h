@@ -14,8 +14,12 @@
  *     (1) a pool of timing-disabled hipEvent_t sets, leased per sd_qwen3_backward* / sd_attn_bwd2 call and per device (two
  *     concurrent backward calls never share an event); (2) the sd_prof_* accumulators (only between
  *     sd_prof_begin/end); (3) measurement switches meant for tests and benchmarks, not for production use:
- *     sd_gemm_force_variant(), sd_debug_cu_budget() and the environment variables SD_OVERLAP_MASK, SD_FUSE_STUDENT_SWIGLU, SD_GEMM_NO_P256,
- *     SD_GEMM_P256_MIN_TILES, SD_GEMM_NO_PERSIST, SD_GEMM_GROUP_M, SD_TOPK_NT (A/B switches, each read once);
+ *     sd_gemm_force_variant(), sd_attn_force_variant(), sd_debug_cu_budget() and the environment variables SD_OVERLAP_MASK,
+ *     SD_FUSE_STUDENT_SWIGLU, SD_GEMM_NO_P256, SD_GEMM_P256_MIN_TILES, SD_GEMM_P256_PAIR, SD_GEMM_P1, SD_GEMM_NO_PERSIST,
+ *     SD_GEMM_GROUP_M, SD_SPLITK_MIN_KT, SD_SPLITK_MIN_SLICE, SD_TN_SHARE, SD_TN_STAG_MIN, SD_ATTN_CLASSIC, SD_QK_BWD_BLOCKS, SD_TOPK_NT (A/B
+ *     switches, each read once), SD_FWD_KSPLIT (K-sliced o / down projections of an inference forward, read per call, off
+ *     by default) and SD_GEMM_CU_BUDGET (workgroups of the backward's persistent weight-gradient launches in a multi-GPU
+ *     run, off by default);
  *   - return value: SD_OK (0), a negative SD_ERR_* code, or a positive hipError_t from the launch.
  */
 #pragma once
