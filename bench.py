@@ -449,7 +449,6 @@ def main():
                 # loss match on IDENTICAL inputs: the HIP path on the very sample (weights, ids) the oracle just ran
                 student.load_hf_state_dict(sw)
                 teacher.load_hf_state_dict(tw)
-                del sw, tw
                 gb = {k: v.to(dev) for k, v in cbatch.items()}
                 student.zero_grad()
                 rows, row_labels = ops.loss_rows(gb["labels"])
@@ -464,23 +463,42 @@ def main():
                 res["loss_match"] = {"hip_bf16": g4, "oracle_fp32": w4, "rel_err_total": abs(g4[0] - w4[0]) / abs(w4[0]),
                                      "tolerance": 2e-2, "sample": "the cpu_baseline sample: same weights (bf16-rounded), same "
                                      "ids, full-shape teacher + student", "ok": abs(g4[0] - w4[0]) <= 2e-2 * abs(w4[0])}
-                # gradient match at FULL depth (28 layers): the oracle's backward of that same sample against the HIP
-                # backward, per tensor: norm ratio within 8e-2 and cosine >= 0.99 (the tolerances of the C1 tests)
+                # gradient match at FULL depth (28 layers) WITH an error budget: the oracle's fp32 backward of that same
+                # sample against the HIP backward, per tensor, next to the same step through the oracle's bf16-storage
+                # mode (oracle/qwen3.py: bf16 rounding at the HIP path's storage points, forward and backward) --
+                # err = relative L2 error against the fp32 oracle; ok = err(HIP) <= 1.5 x err(bf16-storage oracle)
                 got[0].backward()
                 torch.cuda.synchronize()
+                from oracle import qwen3 as Q
+                from oracle import step as S
+                t0 = time.time()
+                c16 = S.distill_step(sw, Q.STUDENT_06B, tw, Q.TEACHER_17B, cbatch, 2.0, 0.5, top_k=args.top_k,
+                                     acc=torch.float32, storage="bf16")
+                t16 = time.time() - t0
+                names = ("model.embed_tokens.weight", "model.layers.0.self_attn.q_proj.weight",
+                         "model.layers.13.mlp.gate_proj.weight", "model.layers.27.mlp.down_proj.weight",
+                         "model.layers.27.input_layernorm.weight", "model.norm.weight")
+                budget = S.grad_error_budget({n: student._params[n].grad for n in names}, cout["grads"], c16["grads"], names)
                 gm, ok_all = {}, True
-                for name in ("model.embed_tokens.weight", "model.layers.0.self_attn.q_proj.weight",
-                             "model.layers.13.mlp.gate_proj.weight", "model.layers.27.mlp.down_proj.weight",
-                             "model.layers.27.input_layernorm.weight", "model.norm.weight"):
+                for name in names:
                     ref_g = cout["grads"][name].double().reshape(-1)
                     hip_g = student._params[name].grad.detach().double().cpu().reshape(-1)
                     rn, hn = float(ref_g.norm()), float(hip_g.norm())
                     cos = float(torch.dot(ref_g, hip_g) / max(rn * hn, 1e-300))
-                    ok = abs(hn - rn) <= 8e-2 * rn and cos >= 0.99
+                    bud = budget[name]
+                    ok = bud["err_hip"] <= 1.5 * bud["err_bf16_oracle"] and cos >= 0.99
                     ok_all &= ok
-                    gm[name] = {"norm_hip": hn, "norm_oracle": rn, "cosine": cos, "ok": ok}
-                res["grad_match"] = {"tensors": gm, "tolerance": {"norm_rel": 8e-2, "cosine_min": 0.99}, "ok": ok_all,
-                                     "sample": "same sample as loss_match; oracle = fp32 autograd through 28 layers"}
+                    gm[name] = {"norm_hip": hn, "norm_oracle": rn, "cosine": cos, "err_hip": bud["err_hip"],
+                                "err_bf16_oracle": bud["err_bf16_oracle"], "ratio": bud["ratio"], "ok": ok}
+                res["grad_match"] = {"tensors": gm, "worst_ratio": max(v["ratio"] for v in gm.values()),
+                                     "tolerance": {"err_hip_over_err_bf16_oracle_max": 1.5, "cosine_min": 0.99},
+                                     "ok": ok_all,
+                                     "bf16_oracle_loss": float(c16["total"]),
+                                     "sample": "same sample as loss_match; err = relative L2 error against the fp32 oracle "
+                                               "(autograd through 28 layers); bf16 oracle = the same step with bf16 rounding "
+                                               f"at the HIP path's storage points ({t16:.1f} s of host time, not part of "
+                                               "cpu_baseline)"}
+                del sw, tw
             except Exception as e:  # never lose the GPU line to a host-side problem
                 res.setdefault("cpu_baseline", {"value": None, "error": repr(e)})
                 res["loss_match"] = {"error": repr(e)}

@@ -21,6 +21,14 @@ Shapes of the teacher: /root/reference/soulxpodcast/config.py:12-42.
 Weights are a flat ``dict[str, Tensor]`` with HF state-dict key names, so the
 same dict drives HF (when pinning the oracle), this oracle, and the HIP model.
 Gradients are taken with torch autograd over this forward.
+
+``storage="bf16"`` (round 4) is the ERROR-BUDGET mode: the same fp32 arithmetic, but every tensor
+the HIP path keeps in HBM as bf16 (normalised rows, q|k|v, rotated q|k, softmax probabilities handed to the P.V
+product, attention output, both residual sums, gate, up, act, final norm, logits) is rounded to bf16 where the HIP
+path stores it -- and, through ``_RoundBF16.backward``, so is the gradient that flows back through the same point
+(the HIP backward stores those gradients as bf16 too).  It is NOT a bit-exact emulation (summation orders differ);
+it measures how much of |HIP - fp32| is plain bf16 storage noise, so that the GPU tests can assert
+``err(HIP, fp32) <= 1.5 * err(bf16-storage oracle, fp32)`` per tensor instead of a bare cosine.
 """
 from __future__ import annotations
 
@@ -102,13 +110,30 @@ def init_weights(shape: Qwen3Shape, seed: int = 0, std: float = 0.02, norm_jitte
     return w
 
 
-def rms_norm(x, w, eps):
+class _RoundBF16(torch.autograd.Function):
+    """y = bf16(x) in the forward, dx = bf16(dy) in the backward: one bf16 STORAGE point of the HIP path."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(g.dtype)
+
+
+def _st(x, storage):
+    return _RoundBF16.apply(x) if storage == "bf16" else x
+
+
+def rms_norm(x, w, eps, storage=None):
     """modeling_qwen3.py:59-64: fp32 statistics, cast back, THEN multiply by the gain."""
     dt = x.dtype
     xf = x.to(torch.float32)
     var = xf.pow(2).mean(-1, keepdim=True)
     xf = xf * torch.rsqrt(var + eps)
-    return w * xf.to(dt)
+    # HF in bf16 rounds at the cast AND after the gain; the HIP kernels do the same (sd_elementwise.hip, EPI 4)
+    return _st(w * _st(xf.to(dt), storage), storage)
 
 
 def rope_tables(T, d, theta, dtype):
@@ -128,7 +153,7 @@ def apply_rope(x, cos, sin):
     return x * cos[None, None] + rot * sin[None, None]
 
 
-def attention(q, k, v, key_len=None):
+def attention(q, k, v, key_len=None, storage=None):
     """Causal GQA attention, fp32 softmax (modeling_qwen3.py:185-207).
 
     q [B,Hq,T,d], k/v [B,Hkv,T,d]; ``key_len`` [B] masks right padding keys.
@@ -144,11 +169,12 @@ def attention(q, k, v, key_len=None):
         mask = mask & kk[:, None, None, :]
     s = s.masked_fill(~mask, torch.finfo(s.dtype).min)
     p = torch.softmax(s, dim=-1, dtype=torch.float32).to(q.dtype)
-    return p @ v
+    return _st(p, storage) @ v  # flash kernels (and the HIP one) hand P to the matrix unit as bf16
 
 
-def forward(w, shape: Qwen3Shape, input_ids, attention_mask=None, return_hidden=False):
-    """input_ids [B,T] -> logits [B,T,V] in the dtype of the weights."""
+def forward(w, shape: Qwen3Shape, input_ids, attention_mask=None, return_hidden=False, storage=None):
+    """input_ids [B,T] -> logits [B,T,V] in the dtype of the weights.  storage="bf16": see the module docstring."""
+    st = lambda t: _st(t, storage)  # noqa: E731
     B, T = input_ids.shape
     Hq, Hkv, d = shape.num_attention_heads, shape.num_key_value_heads, shape.head_dim
     eps = shape.rms_norm_eps
@@ -160,26 +186,26 @@ def forward(w, shape: Qwen3Shape, input_ids, attention_mask=None, return_hidden=
     for l in range(shape.num_hidden_layers):
         p = f"model.layers.{l}."
         r = x
-        xn = rms_norm(x, w[p + "input_layernorm.weight"], eps)
-        q = (xn @ w[p + "self_attn.q_proj.weight"].T).view(B, T, Hq, d)
-        k = (xn @ w[p + "self_attn.k_proj.weight"].T).view(B, T, Hkv, d)
-        v = (xn @ w[p + "self_attn.v_proj.weight"].T).view(B, T, Hkv, d)
-        q = rms_norm(q, w[p + "self_attn.q_norm.weight"], eps).transpose(1, 2)
-        k = rms_norm(k, w[p + "self_attn.k_norm.weight"], eps).transpose(1, 2)
+        xn = rms_norm(x, w[p + "input_layernorm.weight"], eps, storage)
+        q = st(xn @ w[p + "self_attn.q_proj.weight"].T).view(B, T, Hq, d)
+        k = st(xn @ w[p + "self_attn.k_proj.weight"].T).view(B, T, Hkv, d)
+        v = st(xn @ w[p + "self_attn.v_proj.weight"].T).view(B, T, Hkv, d)
+        q = rms_norm(q, w[p + "self_attn.q_norm.weight"], eps, storage).transpose(1, 2)
+        k = rms_norm(k, w[p + "self_attn.k_norm.weight"], eps, storage).transpose(1, 2)
         v = v.transpose(1, 2)
-        q = apply_rope(q, cos, sin)
-        k = apply_rope(k, cos, sin)
-        o = attention(q, k, v, key_len).transpose(1, 2).reshape(B, T, Hq * d)
-        x = r + o @ w[p + "self_attn.o_proj.weight"].T
+        q = st(apply_rope(q, cos, sin))
+        k = st(apply_rope(k, cos, sin))
+        o = st(attention(q, k, v, key_len, storage)).transpose(1, 2).reshape(B, T, Hq * d)
+        x = st(r + o @ w[p + "self_attn.o_proj.weight"].T)
         r = x
-        xn = rms_norm(x, w[p + "post_attention_layernorm.weight"], eps)
-        gate = xn @ w[p + "mlp.gate_proj.weight"].T
-        up = xn @ w[p + "mlp.up_proj.weight"].T
-        x = r + (torch.nn.functional.silu(gate) * up) @ w[p + "mlp.down_proj.weight"].T
+        xn = rms_norm(x, w[p + "post_attention_layernorm.weight"], eps, storage)
+        gate = st(xn @ w[p + "mlp.gate_proj.weight"].T)
+        up = st(xn @ w[p + "mlp.up_proj.weight"].T)
+        x = st(r + st(torch.nn.functional.silu(gate) * up) @ w[p + "mlp.down_proj.weight"].T)
         hiddens.append(x)
-    x = rms_norm(x, w["model.norm.weight"], eps)
+    x = rms_norm(x, w["model.norm.weight"], eps, storage)
     head = emb if shape.tie_word_embeddings else w["lm_head.weight"]
-    logits = x @ head.T
+    logits = st(x @ head.T)
     if return_hidden:
         return logits, hiddens
     return logits

@@ -69,19 +69,30 @@ def collate(features, pad_token_id, speech_bos_id, pad_to_multiple_of=None):
 
 
 def distill_step(student_w, student_shape, teacher_w, teacher_shape, batch, temperature=2.0, alpha=0.5,
-                 top_k=100, is_quantized_teacher=False, with_grad=True, acc=torch.float64):
-    """One compute_loss (+ backward).  Returns dict(total, task, distill, teacher, grads, logits)."""
+                 top_k=100, is_quantized_teacher=False, with_grad=True, acc=torch.float64, storage=None):
+    """One compute_loss (+ backward).  Returns dict(total, task, distill, teacher, grads, logits).
+
+    storage="bf16": the error-budget mode of oracle/qwen3.py -- weights rounded to bf16 (the HIP model keeps bf16
+    parameters, train.py:174), activations and their gradients rounded at the HIP path's storage points, parameter
+    gradients rounded to bf16 at the end (the flat bf16 gradient buffer); the loss itself stays fp32 on the (rounded)
+    logits, as in the HIP kernels.
+    """
+    if storage == "bf16":
+        student_w = {k: v.to(torch.bfloat16).to(v.dtype) for k, v in student_w.items()}
+        if teacher_w is not None:
+            teacher_w = {k: v.to(torch.bfloat16).to(v.dtype) for k, v in teacher_w.items()}
     sw = {k: v.detach().clone().requires_grad_(with_grad) for k, v in student_w.items()}
-    logits = Q.forward(sw, student_shape, batch["input_ids"], batch.get("attention_mask"))
+    logits = Q.forward(sw, student_shape, batch["input_ids"], batch.get("attention_mask"), storage=storage)
     tkv, tki = batch.get("teacher_top_k_v"), batch.get("teacher_top_k_i")
     t_logits = None
     if tkv is None and teacher_w is not None:
         with torch.no_grad():
             if batch.get("teacher_input_ids") is not None:
                 t_logits = Q.forward(teacher_w, teacher_shape, batch["teacher_input_ids"],
-                                     batch.get("teacher_attention_mask"))
+                                     batch.get("teacher_attention_mask"), storage=storage)
             else:
-                t_logits = Q.forward(teacher_w, teacher_shape, batch["input_ids"], batch.get("attention_mask"))
+                t_logits = Q.forward(teacher_w, teacher_shape, batch["input_ids"], batch.get("attention_mask"),
+                                     storage=storage)
     if t_logits is not None and tkv is None and not is_quantized_teacher and top_k > 0:
         tkv, tki = L.extract_topk(t_logits, top_k, vocab_size=logits.shape[-1])
         t_logits = None
@@ -92,5 +103,19 @@ def distill_step(student_w, student_shape, teacher_w, teacher_shape, batch, temp
            "teacher": teacher.detach(), "logits": logits.detach(), "top_k_v": tkv, "top_k_i": tki}
     if with_grad and total.requires_grad:
         total.backward()
-        out["grads"] = {k: v.grad for k, v in sw.items()}
+        out["grads"] = {k: (v.grad.to(torch.bfloat16).to(v.grad.dtype) if storage == "bf16" else v.grad)
+                        for k, v in sw.items()}
+    return out
+
+
+def grad_error_budget(hip_grads, fp32_grads, bf16_grads, names=None):
+    """Per tensor: relative L2 error of the HIP gradient and of the bf16-storage oracle's gradient, both against the
+    fp32 oracle, and their ratio (assert ratio <= 1.5).  All arguments: dict name -> tensor."""
+    out = {}
+    for k in (names or fp32_grads.keys()):
+        ref = fp32_grads[k].double().reshape(-1)
+        rn = float(ref.norm())
+        eh = float((hip_grads[k].detach().double().cpu().reshape(-1) - ref).norm()) / max(rn, 1e-300)
+        eb = float((bf16_grads[k].double().reshape(-1) - ref).norm()) / max(rn, 1e-300)
+        out[k] = {"err_hip": eh, "err_bf16_oracle": eb, "ratio": eh / max(eb, 1e-300)}
     return out

@@ -328,7 +328,9 @@ int run_fwd(const void* S, const void* Tl, const void* topv, const void* topi, c
             void* stats, float* out, int B, int Tlen, int V, int K, float temperature, float alpha, hipStream_t st) {
   const int rows = Tlen ? B * Tlen : B;  // Tlen == 0: B pre-selected rows
   SdProfScope prof(SD_K_LOSS_FWD, (double)rows * V * sizeof(T) * (Tl ? 2 : 1), st);
-  SD_PROF_LABEL("kd_fwd_kernel<%s, %s>", sizeof(T) == 2 ? "__bf16" : "float", temperature == 2.0f ? "true" : "false");
+  // the symbol as rocprofv3 --kernel-trace prints it: kd_fwd_kernel<T, T2, NF, DENSE> (same dispatch as below)
+  SD_PROF_LABEL("kd_fwd_kernel<%s, %s, %d, %s>", sizeof(T) == 2 ? "__bf16" : "float", temperature == 2.0f ? "true" : "false",
+                (Tl || K <= 512) ? 512 : 1024, Tl ? "true" : "false");
 #define SD_KD_FWD(T2_, NF_, DENSE_)                                                                                      \
   hipLaunchKernelGGL((kd_fwd_kernel<T, T2_, NF_, DENSE_>), dim3(rows), dim3(NF_), 0, st, (const T*)S, (const T*)Tl,        \
                      (const _Float16*)topv, (const int32_t*)topi, labels, mask, (RowStats*)stats, rows, Tlen, V, K,          \

@@ -14,7 +14,7 @@ Weight decay applies to matrices only (norm gains are excluded, as HF's paramete
 """
 import torch
 
-from . import ops
+from . import _lib, ops
 
 
 class FlatAdamW(torch.optim.Optimizer):
@@ -25,7 +25,7 @@ class FlatAdamW(torch.optim.Optimizer):
         self.exp_avg = torch.zeros_like(model.flat)
         self.exp_avg_sq = torch.zeros_like(model.flat)
         self._sumsq = torch.zeros(1, dtype=torch.float32, device=model.flat.device)
-        self._partials = torch.empty(2048, dtype=torch.float32, device=model.flat.device)  # sd_sumsq_bf16 scratch, this optimizer's own
+        self._partials = torch.empty(_lib.SUMSQ_PARTIALS, dtype=torch.float32, device=model.flat.device)  # sd_sumsq_bf16 scratch, this optimizer's own
         self._step = 0
         self._measured_clip = None  # set by grad_norm() for the following step()
         # contiguous runs of matrices / gains in the flat layout (for decay on matrices only)

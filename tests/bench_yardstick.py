@@ -1,0 +1,137 @@
+"""GPU measurement (not a pytest, never on the product path): an INDEPENDENT yardstick for the in-tree GEMM kernels.
+
+For every GEMM shape of one BASELINE-config-2 step (teacher / student q|k|v, o, gate|up, down, both lm_heads at
+R = 1536 rows, the student's dX and dW GEMMs) and the config-5 shapes (M = 32 768) it times
+  * the vendor GEMM behind ``torch.matmul`` (hipBLASLt and rocBLAS, whichever torch can select), and
+  * the in-tree kernel the library dispatches for the same operands (``ops.gemm`` = ``sd_gemm_bf16``),
+on the same tensors, weight-side operand rotated through > 600 MB of copies so that it is HBM-cold as in the step
+(every layer has its own weights).  Output: ``gpurun_out/yardstick.json``.  Run under ``rocprofv3 --kernel-trace`` the
+same script yields the vendor kernel NAMES (the tile shape is in the name): ``scripts/yardstick_join.py`` joins the two.
+
+VERDICT r3 item 1(a): is the in-tree K loop at a hardware ceiling ("operand-stream roofline") or only
+at the ceiling of its own structure?  A vendor kernel that is > 10 % faster on a big shape falsifies the former.
+"""
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from speech_distill_amd import ops  # noqa: E402
+
+dev = torch.device("cuda:0")
+
+
+def timeit(fn, iters, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters * 1e3  # us
+
+
+def shapes():
+    V, R = 159488, 1536
+    out = []
+    for tag, h, inter in (("student", 1024, 3072), ("teacher", 2048, 6144)):
+        for M, cfg in ((2048, "c2"), (32768, "c5")):
+            if cfg == "c5" and tag == "student":
+                continue
+            for name, N, K in (("qkv", 4096, h), ("o", h, 2048), ("gu", 2 * inter, h), ("down", h, inter)):
+                out.append((f"{cfg}.{tag}.{name}.fwd", "NT", M, N, K))
+                if tag == "student":
+                    # dX [M,K] = dY [M,N] . W [N,K]  -> NN with contraction N
+                    out.append((f"{cfg}.{tag}.{name}.dX", "NN", M, K, N))
+                    # dW [N,K] = dY^T [N,M] . X [M,K] -> TN with contraction M
+                    out.append((f"{cfg}.{tag}.{name}.dW", "TN", N, K, M))
+        out.append((f"c2.{tag}.lm_head.fwd", "NT", R, V, h))
+        if tag == "student":
+            out.append((f"c2.{tag}.lm_head.dX", "NN", R, h, V))
+            out.append((f"c2.{tag}.lm_head.dW", "TN", V, h, R))
+    # config 5: the teacher's head runs on row chunks (tests/bench_c5.py); one 8 192-row chunk
+    out.append(("c5.teacher.lm_head.fwd", "NT", 8192, V, 2048))
+    return out
+
+
+def main():
+    only = [a for a in sys.argv[1:] if not a.startswith("--")]
+    libs = []
+    for name in ("hipblaslt", "rocblas"):
+        try:
+            torch.backends.cuda.preferred_blas_library(name if name != "rocblas" else "cublas")
+            libs.append(name)
+        except Exception as e:  # noqa: BLE001
+            print(f"# blas library {name}: not selectable ({e})", flush=True)
+    g = torch.Generator(device=dev).manual_seed(0)
+    rows = []
+    for name, form, m, n, k in shapes():
+        if only and not any(o in name for o in only):
+            continue
+        ta, tb = form == "TN", form in ("NN", "TN")
+        a = (torch.randn((k, m) if ta else (m, k), device=dev, generator=g)).bfloat16()
+        b = (torch.randn((k, n) if tb else (n, k), device=dev, generator=g)).bfloat16()
+        c = torch.empty(m, n, device=dev, dtype=torch.bfloat16)
+        w_is_b = form != "TN"  # NT / NN: B is the weight; TN (dW): both operands are activations (warm in the step too)
+        ncopy = max(2, int(600e6 // (b.numel() * 2)) + 1) if w_is_b else 1
+        bs = [b] + [b.clone() for _ in range(ncopy - 1)]
+        rot = [0]
+        am = a.t() if ta else a
+
+        def nxt():
+            rot[0] = (rot[0] + 1) % ncopy
+            return bs[rot[0]]
+
+        iters = 6 if max(m, n, k) > 100000 or m >= 32768 else 25
+        row = {"name": name, "form": form, "M": m, "N": n, "K": k, "gflop": 2.0 * m * n * k / 1e9}
+        line = f"{name:28s} {form} M={m:6d} N={n:6d} K={k:6d}"
+        for lib in libs:
+            torch.backends.cuda.preferred_blas_library(lib if lib != "rocblas" else "cublas")
+
+            def vendor():
+                bb = nxt()
+                torch.matmul(am, bb if tb else bb.t(), out=c)
+            try:
+                us = timeit(vendor, iters)
+            except Exception as e:  # noqa: BLE001
+                print(f"# {name} {lib}: {e}", flush=True)
+                continue
+            row[lib + "_us"] = round(us, 2)
+            row[lib + "_tflops"] = round(row["gflop"] / us * 1e3 / 1e3, 1)
+            line += f"  {lib}:{us:8.1f}us {row[lib + '_tflops']:6.0f}TF"
+        for sk in ([False, True] if (form == "NN" and k >= 2048) else [False]):
+            def intree():
+                ops.gemm(a, nxt(), ta, tb, out=c, split_k=sk)
+            us = timeit(intree, iters)
+            key = "intree_splitk" if sk else "intree"
+            row[key + "_us"] = round(us, 2)
+            row[key + "_tflops"] = round(row["gflop"] / us * 1e3 / 1e3, 1)
+            line += f"  {key}:{us:8.1f}us {row[key + '_tflops']:6.0f}TF"
+        # same result as the vendor library (bf16 output of an fp32 accumulation; summation order differs)
+        ops.gemm(a, bs[0], ta, tb, out=c)
+        got = c.float()
+        torch.matmul(am, bs[0] if tb else bs[0].t(), out=c)
+        err = float((got - c.float()).abs().max() / c.float().abs().max())
+        row["max_rel_diff_vs_vendor"] = err
+        best_v = min(row[x + "_us"] for x in libs if x + "_us" in row)
+        best_i = min(row[x] for x in ("intree_us", "intree_splitk_us") if x in row)
+        row["vendor_over_intree"] = round(best_i / best_v, 3)  # > 1: the vendor kernel is faster
+        line += f"  intree/vendor time = {row['vendor_over_intree']:.3f}  diff {err:.1e}"
+        rows.append(row)
+        print(line, flush=True)
+        del a, b, c, bs, am
+        torch.cuda.empty_cache()
+    os.makedirs("gpurun_out", exist_ok=True)
+    json.dump({"device": torch.cuda.get_device_name(0), "torch": torch.__version__, "hip": torch.version.hip,
+               "note": "us per launch, torch.cuda events around 6-25 back-to-back launches, weight operand HBM-cold "
+                       "(rotated through > 600 MB of copies); vendor = torch.matmul -> hipBLASLt / rocBLAS",
+               "rows": rows}, open("gpurun_out/yardstick.json", "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()

@@ -830,8 +830,8 @@ def test_adamw_and_clip(ops):
 # ------------------------------------------------------------------------------------------ loss rows
 @pytest.mark.parametrize("B,T", [(1, 7), (4, 512), (3, 341), (5, 1000), (2, 2048)])
 def test_loss_rows_kernel_equals_the_reference_rule(ops, B, T):
-    """sd_loss_rows (one launch) == the shift / -100 / speech-mask rule of distillation_loss.py:31-45, which the CPU
-    branch of ops.loss_rows states with plain torch ops: same rows in the same order, same predicted labels; bit-exact
+    """sd_loss_rows (one launch) == the shift / -100 / speech-mask rule of distillation_loss.py:31-45 as the ORACLE
+    states it (oracle/distill_loss.py::_rows): same rows in the same order, same predicted labels; bit-exact
     (index work).  Also: no valid row, every row valid, and the right-padding check of both attention masks."""
     g = torch.Generator().manual_seed(B * T)
     labels = torch.randint(0, 1000, (B, T), generator=g)
@@ -839,10 +839,21 @@ def test_loss_rows_kernel_equals_the_reference_rule(ops, B, T):
     speech = (torch.rand(B, T, generator=g) < 0.7).long()
     lens = torch.randint(1, T + 1, (B,), generator=g)
     am = (torch.arange(T)[None, :] < lens[:, None]).long()
+    from oracle.distill_loss import _rows
+
+    def oracle_rows(lab, sm):
+        # the ORACLE's statement of the rule (oracle/distill_loss.py::_rows, distillation_loss.py:31-45): positions of
+        # the shifted view [B, T-1] that are valid, as flat indices b*T+t into the unshifted [B, T] grid, and their labels
+        _, y, valid = _rows(torch.zeros(B, T, 1), lab.long(), sm)
+        pos = torch.nonzero(valid.reshape(B, T - 1))
+        return pos[:, 0] * T + pos[:, 1], y[valid]
     for sm in (None, speech):
-        want_r, want_l = ops.loss_rows(labels, sm, right_padded=(am, am))          # CPU branch: the rule itself
+        want_r, want_l = oracle_rows(labels, sm)
         got_r, got_l = ops.loss_rows(to_dev(labels), None if sm is None else to_dev(sm), right_padded=(to_dev(am), None))
         assert torch.equal(got_r.cpu(), want_r) and torch.equal(got_l.cpu(), want_l), (B, T, sm is None)
+        # the host logic's CPU branch (used by the trainer for CPU batches) states the same rule
+        cpu_r, cpu_l = ops.loss_rows(labels, sm, right_padded=(am, am))
+        assert torch.equal(cpu_r, want_r) and torch.equal(cpu_l, want_l)
     none_r, none_l = ops.loss_rows(to_dev(torch.full((B, T), -100)))
     assert none_r.numel() == 0 and none_l.numel() == 0
     all_r, all_l = ops.loss_rows(to_dev(torch.ones(B, T, dtype=torch.long)))
@@ -856,7 +867,7 @@ def test_loss_rows_kernel_equals_the_reference_rule(ops, B, T):
         # a float / bool mask is accepted too
         ops.loss_rows(to_dev(labels), to_dev(speech).bool(), right_padded=(to_dev(am).float(),))
     # int32 labels keep their VALUES (token ids and -100), they are not read as a 0/1 mask
-    want_r, want_l = ops.loss_rows(labels, None)
+    want_r, want_l = oracle_rows(labels, None)
     got_r, got_l = ops.loss_rows(to_dev(labels.to(torch.int32)), None)
     assert torch.equal(got_r.cpu(), want_r) and torch.equal(got_l.cpu(), want_l) and got_l.dtype == torch.int64
     # a mask that is not on the labels' [B, T] grid (a teacher batch padded to another length) never reaches the kernel

@@ -9,7 +9,7 @@ import pytest
 import torch
 
 from conftest import load_golden
-from gpu_util import bf, check_close, dev, record, to_dev
+from gpu_util import assert_grad_budget, bf, check_close, dev, record, to_dev
 
 pytestmark = pytest.mark.gpu
 
@@ -181,7 +181,10 @@ def test_c1_compute_loss_matches_reference(sda, mode, top_k, compact):
     """BASELINE config 1: DistillationTrainer.compute_loss on the two fixed micro-batches vs the reference's
     own DistillationTrainer (fp32 CPU) -- loss, the three logged sub-losses, gradient norms and directions;
     with the head applied to the loss rows only (the training default) and to all B*T rows."""
+    from oracle import qwen3 as Q
     tr, student, coll, feats, z = _trainer(sda, top_k)
+    _, st_, te_, sw_, tw_, _, _, _ = _c1(sda)
+    st_, te_ = Q.Qwen3Shape(*st_), Q.Qwen3Shape(*te_)
     tr.compact_head = compact
     logged = []
     tr.log = lambda d, *a, **k: logged.append(dict(d))
@@ -205,6 +208,16 @@ def test_c1_compute_loss_matches_reference(sda, mode, top_k, compact):
             c = _cos(student._params[name].grad, torch.from_numpy(z[f"{mode}_mb{mb}_{key}"]))
             record(f"c1_{mode}_mb{mb}_cos", param=name, cos=c)
             assert c >= 0.99, f"{mode} mb{mb} {name}: cosine {c}"
+        # error budget, every parameter tensor: the fp32 oracle (pinned to the reference's gradients by
+        # tests/test_oracle_qwen3.py / fixture G4) and the same step with bf16 storage rounding
+        from oracle import step as S
+        cb = {k: v.cpu() for k, v in batch.items()}
+        kw = dict(temperature=2.0, alpha=0.5, top_k=top_k, acc=torch.float32)
+        o32 = S.distill_step(sw_, st_, tw_, te_, cb, **kw)
+        o16 = S.distill_step(sw_, st_, tw_, te_, cb, storage="bf16", **kw)
+        np.testing.assert_allclose(float(o32["total"]), ref, rtol=1e-4)  # the oracle IS the reference here
+        assert_grad_budget(f"c1_{mode}_mb{mb}_compact{int(compact)}", {k: p.grad for k, p in student._params.items()},
+                           o32["grads"], o16["grads"])
 
 
 def test_head_rows_equal_full_head(sda):
@@ -339,6 +352,9 @@ def test_real_width_step_vs_oracle(sda):
         gn, rn = float(student._params[k].grad.double().norm()), float(ref["grads"][k].double().norm())
         record("real_width_gnorm", param=k, got=gn, ref=rn)
         assert abs(gn - rn) <= 8e-2 * rn, (k, gn, rn)
+    # error budget on every tensor (the embedding / lm_head gradient included): bf16 storage noise of the same step
+    ref16 = S.distill_step(sw, st, tw, te, batch, 2.0, 0.5, top_k=128, acc=torch.float32, storage="bf16")
+    assert_grad_budget("real_width_step", {k: p.grad for k, p in student._params.items()}, ref["grads"], ref16["grads"])
 
 
 @pytest.mark.parametrize("layers", [1, 2, 5])
@@ -457,7 +473,7 @@ def test_config5_offline_extraction(sda):
     """BASELINE config 5: teacher-only forward at batch 64, seq_len 512 (M = 32 768 rows, 10.4 GB of logits) + top-100.
     Checks on the per-sample unpadded outputs of scripts/extract_teacher_logits.extract: dtypes/shapes as the
     reference stores them (extract_teacher_logits.py:120-129), sortedness, exp(values) is a sub-probability, and
-    the values/indices of sampled rows against torch.topk(log_softmax) computed from the same logits."""
+    the indices (bit-exact) / values of 192 sampled rows against oracle.extract_topk on the same logits."""
     import importlib.util
     import os
     from conftest import ROOT
@@ -478,15 +494,28 @@ def test_config5_offline_extraction(sda):
     assert v[0].dtype == np.float16 and i[0].dtype == np.int32
     vv = np.stack([x[:17] for x in v]).astype(np.float32)
     assert (np.diff(vv, axis=-1) <= 0).all() and np.exp(vv).sum(-1).max() <= 1.0 + 1e-3
+    # Exact check (index work): the SAME B = 64 forward once more with the logits kept, 192 sampled rows (incl. the last
+    # valid position of the two short samples) through oracle.extract_topk -- log-softmax at T = 1, stable descending
+    # sort = ties to the lowest index (extract_teacher_logits.py:114-129) -- indices bit-exact, values to one fp16 ulp
+    # (the kernel's log-sum-exp adds in another order).  The kernels are deterministic, so extract()'s rows are these.
+    from oracle.distill_loss import extract_topk
     with torch.no_grad():
-        logits = teacher(input_ids=to_dev(ids[:2]), attention_mask=to_dev(am[:2])).logits.float()
-    rv, ri = torch.topk(torch.log_softmax(logits, -1), K, dim=-1)
-    got_v = torch.from_numpy(np.stack(v[:2]).astype(np.float32))
-    assert float((got_v - rv.cpu()).abs().max()) <= 1.6e-2  # one fp16 ulp at |log p| ~ 12
-    # bf16 logits tie often: compare as value multisets (indices may differ only inside a tie)
-    same = (torch.from_numpy(np.stack(i[:2])).long() == ri.cpu()).float().mean()
-    record("config5_extract", index_agreement=float(same))
-    assert float(same) > 0.9
+        logits = teacher(input_ids=to_dev(ids), attention_mask=to_dev(am)).logits
+    assert logits.shape == (B, T, 159488)
+    gs = torch.Generator().manual_seed(9)
+    bs = torch.cat([torch.randint(0, B, (190,), generator=gs), torch.tensor([3, 7])])
+    ts = torch.cat([torch.randint(0, 17, (190,), generator=gs), torch.tensor([399, 16])])  # t < 17: valid in every sample
+    rows = logits[to_dev(bs), to_dev(ts)].cpu()
+    del logits
+    want_v, want_i = extract_topk(rows, K)
+    got_v = torch.from_numpy(np.stack([v[int(b)][int(t)] for b, t in zip(bs, ts)]))
+    got_i = torch.from_numpy(np.stack([i[int(b)][int(t)] for b, t in zip(bs, ts)]))
+    n_ties = int((rows.float().sort(-1, descending=True).values[:, :K + 1].diff(dim=-1) == 0).sum())
+    record("config5_extract", rows=int(rows.shape[0]), index_equal=bool(torch.equal(got_i, want_i)), ties_in_top_k=n_ties,
+           max_value_diff=float((got_v.float() - want_v.float()).abs().max()))
+    assert torch.equal(got_i, want_i), "top-K indices differ from oracle.extract_topk"
+    assert n_ties > 0, "bf16 logits at V = 159 488 tie inside the top-100 of some row: the tie rule is exercised"
+    assert float((got_v.float() - want_v.float()).abs().max()) <= 1.6e-2  # one fp16 ulp at |log p| ~ 12
 
 
 def test_extract_script_end_to_end_on_disk(sda, tmp_path, monkeypatch):

@@ -89,3 +89,28 @@ def test_c1_logged_loss_is_sum_over_accumulation():
     z, *_ = _c1()
     np.testing.assert_allclose(z["train_loss_per_step"][0], float(z["sparse_mb0_loss"]) + float(z["sparse_mb1_loss"]),
                                rtol=1e-5)
+
+
+def test_bf16_storage_mode_is_a_noise_model_not_a_different_function():
+    """The error-budget mode of the oracle (storage="bf16"): default mode untouched (the pinned fp32
+    oracle), the bf16-storage run stays within bf16 noise of it (loss to 1e-3, every gradient tensor to
+    1.5e-1 relative L2 and cosine >= 0.985), its gradients are exactly bf16-representable, and the budget helper
+    returns ratio 1 for the noise model against itself."""
+    z, st, te, sw, tw, feats, pad, bos = _c1()
+    batch = S.collate(feats[:4], pad, bos)
+    a = S.distill_step(sw, st, tw, te, batch, 2.0, 0.5, top_k=16, acc=torch.float32)
+    a2 = S.distill_step(sw, st, tw, te, batch, 2.0, 0.5, top_k=16, acc=torch.float32, storage=None)
+    b = S.distill_step(sw, st, tw, te, batch, 2.0, 0.5, top_k=16, acc=torch.float32, storage="bf16")
+    assert float(a["total"]) == float(a2["total"])
+    for k in a["grads"]:  # (two CPU runs differ in the last bits: threaded reductions)
+        assert float((a["grads"][k] - a2["grads"][k]).abs().max()) <= 1e-5 * float(a["grads"][k].abs().max()), k
+    np.testing.assert_allclose(float(b["total"]), float(a["total"]), rtol=1e-3)
+    assert float(b["total"]) != float(a["total"])
+    for k, g in b["grads"].items():
+        r = a["grads"][k].double()
+        err = float((g.double() - r).norm() / r.norm())
+        cos = float((g.double().flatten() @ r.flatten()) / (g.double().norm() * r.norm()))
+        assert 0 < err <= 1.5e-1 and cos >= 0.985, (k, err, cos)
+        assert torch.equal(g, g.bfloat16().float()), k
+    rows = S.grad_error_budget(b["grads"], a["grads"], b["grads"])
+    assert all(abs(v["ratio"] - 1.0) < 1e-12 for v in rows.values())
