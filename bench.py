@@ -85,6 +85,12 @@ def cpu_baseline(sample_T, threads, n_seq=2):
     t0 = time.time()
     out = S.distill_step(sw, Q.STUDENT_06B, tw, Q.TEACHER_17B, batch, 2.0, 0.5, top_k=128, acc=torch.float32)
     dt = time.time() - t0
+    # NOT part of the timed baseline: the same step with bf16 rounding at the HIP path's storage points (oracle/qwen3.py,
+    # storage="bf16") -- the noise yardstick of `grad_match`
+    t0 = time.time()
+    out16 = S.distill_step(sw, Q.STUDENT_06B, tw, Q.TEACHER_17B, batch, 2.0, 0.5, top_k=128, acc=torch.float32,
+                           storage="bf16")
+    out["bf16_storage"] = {"grads": out16["grads"], "total": float(out16["total"]), "seconds": time.time() - t0}
     res = {"value": n_seq * sample_T / dt, "unit": "tokens/s", "cores": threads, "cpu": cpu_model_name(), "kind": "port",
            "sample": f"{n_seq} sequences x {sample_T} tokens (of the 4 x 512 batch), full-shape teacher+student, fp32 "
                      f"arithmetic on bf16-rounded weights, one micro-step incl. backward, {dt:.1f} s",
@@ -469,16 +475,18 @@ def main():
                 # err = relative L2 error against the fp32 oracle; ok = err(HIP) <= 1.5 x err(bf16-storage oracle)
                 got[0].backward()
                 torch.cuda.synchronize()
-                from oracle import qwen3 as Q
-                from oracle import step as S
-                t0 = time.time()
-                c16 = S.distill_step(sw, Q.STUDENT_06B, tw, Q.TEACHER_17B, cbatch, 2.0, 0.5, top_k=args.top_k,
-                                     acc=torch.float32, storage="bf16")
-                t16 = time.time() - t0
+                c16 = cout["bf16_storage"]
                 names = ("model.embed_tokens.weight", "model.layers.0.self_attn.q_proj.weight",
                          "model.layers.13.mlp.gate_proj.weight", "model.layers.27.mlp.down_proj.weight",
                          "model.layers.27.input_layernorm.weight", "model.norm.weight")
-                budget = S.grad_error_budget({n: student._params[n].grad for n in names}, cout["grads"], c16["grads"], names)
+
+                def rel_l2(g, ref):
+                    ref = ref.double().reshape(-1)
+                    return float((g.detach().double().cpu().reshape(-1) - ref).norm() / ref.norm())
+                budget = {n: {"err_hip": rel_l2(student._params[n].grad, cout["grads"][n]),
+                              "err_bf16_oracle": rel_l2(c16["grads"][n], cout["grads"][n])} for n in names}
+                for b_ in budget.values():
+                    b_["ratio"] = b_["err_hip"] / max(b_["err_bf16_oracle"], 1e-300)
                 gm, ok_all = {}, True
                 for name in names:
                     ref_g = cout["grads"][name].double().reshape(-1)
@@ -493,10 +501,10 @@ def main():
                 res["grad_match"] = {"tensors": gm, "worst_ratio": max(v["ratio"] for v in gm.values()),
                                      "tolerance": {"err_hip_over_err_bf16_oracle_max": 1.5, "cosine_min": 0.99},
                                      "ok": ok_all,
-                                     "bf16_oracle_loss": float(c16["total"]),
+                                     "bf16_oracle_loss": c16["total"],
                                      "sample": "same sample as loss_match; err = relative L2 error against the fp32 oracle "
                                                "(autograd through 28 layers); bf16 oracle = the same step with bf16 rounding "
-                                               f"at the HIP path's storage points ({t16:.1f} s of host time, not part of "
+                                               f"at the HIP path's storage points ({c16['seconds']:.1f} s of host time, not part of "
                                                "cpu_baseline)"}
                 del sw, tw
             except Exception as e:  # never lose the GPU line to a host-side problem

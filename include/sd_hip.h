@@ -10,16 +10,11 @@
  *   - every pointer is a DEVICE pointer unless the name ends in _host; bf16 tensors are row-major,
  *     16-byte aligned, leading dimensions are in ELEMENTS and multiples of 8;
  *   - `stream` is a hipStream_t (torch's current stream); launchers never allocate device memory and never
- *     synchronise; scratch comes from the caller (see *_workspace_bytes).  Process state is limited to:
- *     (1) a pool of timing-disabled hipEvent_t sets, leased per sd_qwen3_backward* / sd_attn_bwd2 call and per device (two
- *     concurrent backward calls never share an event); (2) the sd_prof_* accumulators (only between
- *     sd_prof_begin/end); (3) measurement switches meant for tests and benchmarks, not for production use:
- *     sd_gemm_force_variant(), sd_attn_force_variant(), sd_debug_cu_budget() and the environment variables SD_OVERLAP_MASK,
- *     SD_FUSE_STUDENT_SWIGLU, SD_GEMM_NO_P256, SD_GEMM_P256_MIN_TILES, SD_GEMM_P256_PAIR, SD_GEMM_P1, SD_GEMM_NO_PERSIST,
- *     SD_GEMM_GROUP_M, SD_SPLITK_MIN_KT, SD_SPLITK_MIN_SLICE, SD_TN_SHARE, SD_TN_STAG_MIN, SD_ATTN_CLASSIC, SD_QK_BWD_BLOCKS, SD_TOPK_NT (A/B
- *     switches, each read once), SD_FWD_KSPLIT (K-sliced o / down projections of an inference forward, read per call, off
- *     by default) and SD_GEMM_CU_BUDGET (workgroups of the backward's persistent weight-gradient launches in a multi-GPU
- *     run, off by default);
+ *     synchronise; scratch comes from the caller (see *_workspace_bytes).  Process state reachable from THIS header is
+ *     limited to: (1) a pool of timing-disabled hipEvent_t sets, leased per sd_qwen3_backward* / sd_attn_bwd2 call and per
+ *     device (two concurrent backward calls never share an event); (2) the sd_prof_* accumulators (only between
+ *     sd_prof_begin/end).  The library never reads the environment.  Measurement and test switches (forced kernel variants,
+ *     A/B thresholds, the CU budget of a multi-GPU run) are a separate interface, include/sd_hip_debug.h;
  *   - return value: SD_OK (0), a negative SD_ERR_* code, or a positive hipError_t from the launch.
  */
 #pragma once
@@ -50,8 +45,6 @@ int sd_gemm_bf16(const void* A, const void* B, void* C, const void* R, int M, in
  * write fp32 slabs into `workspace`, summed in a fixed order by a second kernel (deterministic).
  * sd_gemm_splitk_plan returns the number of slices the library would use (1 = no split). */
 int sd_gemm_splitk_plan(int M, int N, int K);
-/* tuning / tests only: force the tile rows (64|128) and LDS ring depth (2..4) of every later GEMM; bm=0 restores the heuristic */
-void sd_gemm_force_variant(int bm, int nst);
 int64_t sd_gemm_splitk_workspace_bytes(int M, int N, int K);
 int sd_gemm_bf16_splitk(const void* A, const void* B, void* C, const void* R, int M, int N, int K, int64_t lda,
                         int64_t ldb, int64_t ldc, int64_t ldr, int trans_a, int trans_b, void* workspace,
@@ -86,26 +79,6 @@ typedef struct {
   int32_t M, N;
 } sd_gemm_problem;
 int sd_gemm_grouped_tn(const sd_gemm_problem* probs, int n, int K, int accumulate, void* stream);
-/* The SAME forward projection of two independent models (student + frozen teacher in lockstep, train.py:54 and
- * train.py:60-69 on one stream; or any two NT GEMMs) as ONE persistent launch: C_p [M,N] = A_p [M,K] . B_p [N,K]^T,
- * p < n <= 2, K % 64 == 0.  nsplit > 1 cuts K into that many slices, each writing an fp32 slab [nsplit][M][N] into
- * `slabs` (summed by the consumer, sd_rmsnorm_fwd_slabs) instead of C.  swiglu != 0: B = [gate rows | up rows] [2I,K],
- * N = 2I, act [M,I] = silu(gate) * up -> out2, gate|up -> C when C != NULL (HF:81-83), nsplit must be 1. */
-typedef struct {
-  const void* A;
-  const void* B;
-  void* C;
-  void* out2;
-  float* slabs;
-  int64_t lda, ldb, ldc;
-  int32_t M, N, K, nsplit;
-} sd_gemm_nt_problem;
-int sd_gemm_grouped_nt(const sd_gemm_nt_problem* probs, int n, int swiglu, void* stream);
-/* cap the workgroups of every later persistent grouped launch (sd_gemm_grouped_nt: measurements, tests/bench_partition.py) and
- * of the backward's persistent weight-gradient launches (sd_gemm_grouped_tn, the TN form of sd_gemm_bf16); 0 = one per CU.
- * The environment variable SD_GEMM_CU_BUDGET sets the same for the weight-gradient launches of a multi-GPU run, where
- * RCCL's kernels hold CUs beside the backward. */
-void sd_debug_cu_budget(int cus);
 /* backward twin: d(gate|up) [M,2I] = SwiGLU'(gate_up) applied to d(act) = dy [M,H] . W_down [H,I], in the epilogue of
  * that GEMM (d(act) is never stored); equals sd_gemm_bf16 (NN) + sd_swiglu_bwd bit for bit. */
 int sd_gemm_swiglu_bwd(const void* dy, const void* wdown, const void* gate_up, void* dgate_up, int M, int I, int H,
@@ -116,11 +89,6 @@ int sd_gemm_qkv_rope(const void* x, const void* wqkv, void* qkv_out, void* qk_ou
 
 /* ---- RMSNorm (HF:59-64).  rstd (fp32 [M], nullable in fwd) is saved for backward. */
 int sd_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int M, int H, float eps, void* stream);
-/* Residual + K-sliced projection + RMSNorm in one pass (HF:304-323): x_out = bf16(resid + sum_s slabs[s]) with slabs fp32
- * [nsplit][M][H] as sd_gemm_grouped_nt leaves them (one rounding of the fp32 sum, as the residual epilogue of the unsplit
- * GEMM); y = RMSNorm(x_out) * w, rstd as sd_rmsnorm_fwd. */
-int sd_rmsnorm_fwd_slabs(const float* slabs, int nsplit, const void* resid, const void* w, void* x_out, void* y, float* rstd,
-                         int M, int H, float eps, void* stream);
 int64_t sd_rmsnorm_bwd_workspace_bytes(int M, int H);
 /* dx = d(norm)/dx . dy (+ dres, nullable: the residual-stream gradient); dw (+)= sum_rows dy * xhat */
 int sd_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, const void* dres, void* dx,
@@ -180,9 +148,6 @@ int sd_rows_scatter(const void* src, const int64_t* rows, void* dst, int n, int 
 int sd_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const int32_t* kv_len, int64_t ldq,
                 int64_t ldk, int64_t ldv, int64_t ldo, int B, int T, int Hq, int Hkv, int head_dim, float scale,
                 void* stream);
-/* measurements / tests only: the forward kernel without (bit 0) / with (bit 1) the in-wave software pipeline at any T
- * (default: with it from T = 1024); both give the same results bit for bit */
-void sd_attn_force_variant(int variant);
 /* delta: fp32 [B,Hq,T] scratch (rowsum(dO*O)).  sd_attn_bwd2: same, with the dQ kernel launched on `side_stream`
  * (nullable) beside the dK/dV kernel -- they only share read-only inputs; `stream` has joined when it returns. */
 int sd_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse,

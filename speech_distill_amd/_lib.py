@@ -64,15 +64,20 @@ STAGE_CB = C.CFUNCTYPE(None, C.c_int, C.c_void_p)
 
 _vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 # name -> (restype, argtypes); must list every symbol include/sd_hip.h declares (tests check this)
+_cp = C.c_char_p
+# include/sd_hip_debug.h: measurement / test switches (not part of the product ABI)
+DEBUG_PROTOTYPES = {
+    "sd_debug_set": (_i, [_cp, _i64]),
+    "sd_debug_get": (_i64, [_cp]),
+    "sd_debug_keys": (_i, [_vp, _i]),
+}
 PROTOTYPES = {
     "sd_abi_version": (_i, []),
     "sd_gemm_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _i64, _i64, _i, _i, _vp]),
-    "sd_gemm_force_variant": (None, [_i, _i]),
     "sd_gemm_splitk_plan": (_i, [_i, _i, _i]),
     "sd_gemm_splitk_workspace_bytes": (_i64, [_i, _i, _i]),
     "sd_gemm_bf16_splitk": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _i64, _i64, _i, _i, _vp, _i64, _vp]),
     "sd_rmsnorm_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
-    "sd_rmsnorm_fwd_slabs": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "sd_rmsnorm_bwd_workspace_bytes": (_i64, [_i, _i]),
     "sd_rmsnorm_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _vp]),
     "sd_gemm_swiglu": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
@@ -89,7 +94,6 @@ PROTOTYPES = {
     "sd_embedding_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "sd_embedding_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _vp]),
     "sd_attn_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _i, _f, _vp]),
-    "sd_attn_force_variant": (None, [_i]),
     "sd_attn_bwd": (_i, [_vp] * 11 + [_i64] * 7 + [_i, _i, _i, _i, _i, _f, _vp]),
     "sd_attn_bwd2": (_i, [_vp] * 11 + [_i64] * 7 + [_i, _i, _i, _i, _i, _f, _vp, _vp]),
     "sd_logsoftmax_topk": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _i, _i, _vp]),
@@ -97,8 +101,6 @@ PROTOTYPES = {
     "sd_kdloss_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _i, _vp]),
     "sd_kdloss_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _i, _vp]),
     "sd_gemm_grouped_tn": (_i, [_vp, _i, _i, _i, _vp]),
-    "sd_gemm_grouped_nt": (_i, [_vp, _i, _i, _vp]),
-    "sd_debug_cu_budget": (None, [_i]),
     "sd_gemm_swiglu_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "sd_gemm_odx_delta": (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _i, _i, _i, _i, _vp]),
     "sd_kdloss_fwd_rows": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _vp]),
@@ -137,11 +139,47 @@ def load_lib():
             f"{path} not found: build it with `make -C speech_distill_amd/csrc` (hipcc --offload-arch=gfx950). "
             "speech_distill_amd has no CPU fallback.")
     lib = C.CDLL(path)
-    for name, (res, args) in PROTOTYPES.items():
+    for name, (res, args) in list(PROTOTYPES.items()) + list(DEBUG_PROTOTYPES.items()):
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = res, args
     _LIB = lib
+    # The HOST reads the environment, the library never does: SD_GEMM_CU_BUDGET caps the backward's persistent launches of a
+    # multi-GPU run; the others are the A/B switches of tests/bench_*.py; SD_DEBUG="key=v,key=v" sets
+    # any key of include/sd_hip_debug.h.
+    for env, key in _ENV_KEYS.items():
+        if os.environ.get(env):
+            debug_set(key, int(os.environ[env]))
+    for item in filter(None, os.environ.get("SD_DEBUG", "").split(",")):
+        k, v = item.split("=")
+        debug_set(k.strip(), int(v))
     return lib
+
+
+_ENV_KEYS = {"SD_GEMM_CU_BUDGET": "gemm.cu_budget", "SD_GEMM_NO_P256": "gemm.no_p256", "SD_GEMM_NO_PERSIST": "gemm.no_persist",
+             "SD_GEMM_P256_MIN_TILES": "gemm.p256_min_tiles", "SD_GEMM_GROUP_M": "gemm.group_m",
+             "SD_TN_STAG_MIN": "gemm.tn_stag_min", "SD_SPLITK_MIN_KT": "gemm.splitk_min_kt",
+             "SD_SPLITK_MIN_SLICE": "gemm.splitk_min_slice", "SD_FUSE_STUDENT_SWIGLU": "model.fuse_student_swiglu",
+             "SD_OVERLAP_MASK": "model.overlap_mask", "SD_TOPK_NT": "topk.nt", "SD_QK_BWD_BLOCKS": "qk_bwd.blocks"}
+
+
+def debug_set(key: str, value: int):
+    """include/sd_hip_debug.h: sd_debug_set(key, value); raises on an unknown key."""
+    rc = load_lib().sd_debug_set(key.encode(), int(value))
+    if rc != 0:
+        raise SdHipError(f"sd_debug_set({key!r}) failed: {ERRORS.get(rc, rc)}")
+
+
+def debug_get(key: str) -> int:
+    return int(load_lib().sd_debug_get(key.encode()))
+
+
+def gemm_force_variant(bm: int, nst: int):
+    """tests / benchmarks: force tile rows and ring depth of every later GEMM (0, 0 = heuristic).  nst | 0x100: checked
+    (pointer) staging; nst | 0x400: gemm_p256_kernel with 32-deep half-line stages."""
+    debug_set("gemm.checked_staging", 1 if nst & 0x100 else 0)
+    debug_set("gemm.p256_unpaired", 1 if nst & 0x400 else 0)
+    debug_set("gemm.force_bm", bm)
+    debug_set("gemm.force_nst", (nst & 0xff) if bm else 0)
 
 
 def check(rc: int, what: str):

@@ -20,6 +20,7 @@
 #include "sd_common.cuh"
 #include "../../include/sd_hip.h"
 #include "sd_prof.h"
+#include "sd_debug.h"
 #include "sd_events.h"
 
 namespace {
@@ -981,8 +982,7 @@ extern "C" void sd_debug_attn_stamp_buffer(void* p) { g_attn_stamps = (unsigned 
 
 // bit 0: forward without the in-wave software pipeline (attn_fwd_kernel) at any T; bit 1: with it at any T (default:
 // from T = 1024); tests and A/B measurements
-static int g_attn_variant = 0;
-extern "C" void sd_attn_force_variant(int v) { g_attn_variant = v; }
+// (g_sd_debug.attn_variant, include/sd_hip_debug.h key "attn.variant")
 
 extern "C" int sd_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const int32_t* kv_len,
                            int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int B, int T, int Hq, int Hkv,
@@ -991,13 +991,12 @@ extern "C" int sd_attn_fwd(const void* q, const void* k, const void* v, void* o,
   if (int e = check_common(B, T, Hq, Hkv, ldq, ldk, ldv, ldo)) return e;
   if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) & 15) return SD_ERR_ALIGN;
   SdProfScope prof(SD_K_ATTN_FWD, 2.0 * B * Hq * (double)T * T * D, (hipStream_t)stream);  // 2 products, causal half
-  static const bool classic_env = getenv("SD_ATTN_CLASSIC") && atoi(getenv("SD_ATTN_CLASSIC")) != 0;  // A/B measurements
   const dim3 grid((((T + 63) / 64 + 1) / 2) * Hq * B);
   // Measured (tests/bench_attn_pipe.py, MI355X, 16/8 heads): the pipelined kernel is 3-5 % faster from T = 1024 (21.8 vs
   // 22.2 us at B=2, 32.9 vs 34.6 us at B=1 T=2048, 119 vs 123 us at B=4 T=2048) and ties or loses 0.1-0.5 us below
   // (its prologue computes S^T(0) before the loop and needs tile 1 for the first iteration), so short streams keep the
   // classic kernel.  bit 1 of the variant forces the pipelined one at any T (tests).
-  const bool pipe = (g_attn_variant & 2) || (!classic_env && !(g_attn_variant & 1) && T >= 1024);
+  const bool pipe = (g_sd_debug.attn_variant & 2) || (!(g_sd_debug.attn_variant & 1) && T >= 1024);
   if (pipe) {
     hipLaunchKernelGGL(attn_fwd_pipe_kernel, grid, dim3(512), 0, (hipStream_t)stream, (const bf16*)q, (const bf16*)k,
                        (const bf16*)v, (bf16*)o, lse, kv_len, ldq, ldk, ldv, ldo, T, Hq, Hkv, scale SD_ATT_STAMP_ARG);

@@ -1,0 +1,25 @@
+// Measurement / test switches of the library (include/sd_hip_debug.h: sd_debug_set / sd_debug_get).  One plain struct,
+// defaults = the product behaviour; nothing in the library reads the environment.
+#pragma once
+
+struct SdDebug {
+  // sd_gemm.hip
+  int gemm_force_bm = 0, gemm_force_nst = 0;  // 0 = heuristic; else tile rows (64|128|256) and ring depth (2..4, 9 = staggered)
+  int gemm_checked_staging = 0;               // pointer-based staging with a zero page instead of buffer descriptors
+  int gemm_p256_unpaired = 0;                 // gemm_p256_kernel with 32-deep half-line stages
+  int gemm_cu_budget = 0;                     // workgroups of the backward's persistent weight-gradient launches (0 = one per CU)
+  int gemm_no_persist = 0, gemm_no_p256 = 0;
+  int gemm_p256_min_tiles = 1024;
+  int gemm_group_m = 0;
+  int gemm_tn_stag_min = 1024;
+  int gemm_splitk_min_kt = 96, gemm_splitk_min_slice = 24;
+  // sd_model.hip
+  int model_fuse_student_swiglu = 0;
+  int model_overlap_mask = 31;  // bit0 lm_head dW, bit1 gain reduces, bit2 attention dQ, bit3 grouped per-layer dW, bit4 batched gain reduce
+  int model_no_fold = 0;        // inference forward: run the RMSNorm launches even when folded weights were given
+  // sd_topk.hip / sd_elementwise.hip / sd_attn.hip
+  int topk_nt = 0;
+  int qk_bwd_blocks = 512;
+  int attn_variant = 0;  // bit0: forward without the in-wave pipeline at any T; bit1: with it at any T
+};
+extern SdDebug g_sd_debug;

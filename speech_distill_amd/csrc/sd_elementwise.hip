@@ -13,6 +13,7 @@
 #include "sd_common.cuh"
 #include "../../include/sd_hip.h"
 #include "sd_prof.h"
+#include "sd_debug.h"
 
 namespace {
 
@@ -63,58 +64,6 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const bf16* __restrict
 #pragma unroll
       for (int e = 0; e < 8; ++e) f[e] = g[e] * (float)(bf16)(f[e] * rstd);  // HF: weight * hidden.to(bf16)
       *(bf16x8*)(yr + c) = pack8(f);
-    }
-  }
-}
-
-// The same with the input given as a residual plus the un-reduced output of a K-sliced projection (fp32 slabs
-// [nsplit][M][H] of sd_gemm_grouped_nt): x = bf16(resid + slab_0 + slab_1 + ...) -- one rounding of the fp32 sum, as the
-// residual epilogue of the unsplit GEMM does -- is written to x_out (the residual stream the next block reads), then
-// normalised.  HF:304-323 (residual + projection, then the next RMSNorm), fused into one pass over the row.
-template <int NCH>
-__global__ __launch_bounds__(256) void rmsnorm_fwd_slabs_kernel(const float* __restrict__ slabs, int nsplit,
-                                                                const bf16* __restrict__ resid, const bf16* __restrict__ w,
-                                                                bf16* __restrict__ x_out, bf16* __restrict__ y,
-                                                                float* __restrict__ rstd_out, int M, int H, float eps) {
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= M) return;
-  const int lane = lane_id();
-  bf16x8 xv[NCH];
-  float ss = 0.f;
-#pragma unroll
-  for (int i = 0; i < NCH; ++i) {
-    const int c = lane * 8 + i * 512;
-    if (c < H) {
-      float v[8];
-      unpack8(*(const bf16x8*)(resid + (long)row * H + c), v);
-      float sv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      for (int sp = 0; sp < nsplit; ++sp) {
-        const float* ps = slabs + ((long)sp * M + row) * H + c;
-        const f32x4 a = *(const f32x4*)ps, b = *(const f32x4*)(ps + 4);
-        sv[0] += a[0]; sv[1] += a[1]; sv[2] += a[2]; sv[3] += a[3];
-        sv[4] += b[0]; sv[5] += b[1]; sv[6] += b[2]; sv[7] += b[3];
-      }
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] += sv[e];
-      xv[i] = pack8(v);
-      *(bf16x8*)(x_out + (long)row * H + c) = xv[i];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) { const float f = (float)xv[i][e]; ss += f * f; }
-    }
-  }
-  ss = wave_sum(ss);
-  const float rstd = rsqrtf(ss / (float)H + eps);
-  if (lane == 0 && rstd_out) rstd_out[row] = rstd;
-#pragma unroll
-  for (int i = 0; i < NCH; ++i) {
-    const int c = lane * 8 + i * 512;
-    if (c < H) {
-      float f[8], g[8];
-      unpack8(xv[i], f);
-      unpack8(*(const bf16x8*)(w + c), g);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) f[e] = g[e] * (float)(bf16)(f[e] * rstd);
-      *(bf16x8*)(y + (long)row * H + c) = pack8(f);
     }
   }
 }
@@ -522,22 +471,6 @@ extern "C" int sd_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd
   return 0;
 }
 
-extern "C" int sd_rmsnorm_fwd_slabs(const float* slabs, int nsplit, const void* resid, const void* w, void* x_out, void* y,
-                                    float* rstd, int M, int H, float eps, void* stream) {
-  if (M <= 0 || (H & 7) || nsplit < 1 || !slabs || !resid || !x_out) return SD_ERR_SHAPE;
-  if (H > 4096) return SD_ERR_UNSUPPORTED;
-  if (((uintptr_t)slabs | (uintptr_t)resid | (uintptr_t)w | (uintptr_t)x_out | (uintptr_t)y) & 15) return SD_ERR_ALIGN;
-  const int nch = (H + 511) / 512;
-  SdProfScope prof(SD_K_RMSNORM, (4.0 * nsplit + 6.0) * M * H, ST);
-  SD_PROF_LABEL("rmsnorm_fwd_slabs_kernel<%d>", nch <= 1 ? 1 : nch == 2 ? 2 : nch <= 4 ? 4 : 8);
-#define SD_RMS_FWDS(N) hipLaunchKernelGGL(rmsnorm_fwd_slabs_kernel<N>, dim3((M + 3) / 4), dim3(256), 0, ST, slabs, nsplit, \
-                                          (const bf16*)resid, (const bf16*)w, (bf16*)x_out, (bf16*)y, rstd, M, H, eps)
-  if (nch <= 1) SD_RMS_FWDS(1); else if (nch == 2) SD_RMS_FWDS(2); else if (nch <= 4) SD_RMS_FWDS(4); else SD_RMS_FWDS(8);
-#undef SD_RMS_FWDS
-  SD_CHECK_LAUNCH();
-  return 0;
-}
-
 extern "C" int64_t sd_rmsnorm_bwd_workspace_bytes(int M, int H) {
   const int nb = (M + 3) / 4 < 512 ? (M + 3) / 4 : 512;
   return (int64_t)nb * H * 4;
@@ -644,7 +577,7 @@ extern "C" int sd_qknorm_rope_fwd(const void* qkv, const void* q_gain, const voi
 }
 
 static inline int qk_bwd_blocks(long items, int* ipb) {
-  static const long nblk = getenv("SD_QK_BWD_BLOCKS") ? atol(getenv("SD_QK_BWD_BLOCKS")) : 512;  // A/B measurements
+  const long nblk = g_sd_debug.qk_bwd_blocks > 0 ? g_sd_debug.qk_bwd_blocks : 512;
   long per = (items + nblk - 1) / nblk;
   per = (per + 47) / 48 * 48;  // a whole number of 16-lane-group trips of 3 items (qknorm_rope_bwd_kernel)
   *ipb = (int)per;

@@ -27,6 +27,7 @@
 #include "sd_common.cuh"
 #include "../../include/sd_hip.h"
 #include "sd_prof.h"
+#include "sd_debug.h"
 
 extern "C" __device__ __attribute__((aligned(256))) unsigned char sd_zero_page[1024] = {0};
 
@@ -896,210 +897,6 @@ __global__ __launch_bounds__(768) void gemm_pstag_kernel(const bf16* __restrict_
 #undef SD_STAMP_DUMP
 
 // ---------------------------------------------------------------------------------------------------
-// Persistent 256x128x64 kernel with ONE compute wave per SIMD (4 compute + 4 producer waves).  In gemm_pstag_kernel a
-// K-step is 2 x (LOAD phase | barrier | 32-MFMA phase | barrier): the two waves of a SIMD alternate, the matrix pipe
-// idles across four barriers per step and a 32-MFMA phase takes ~700 cycles beside the partner's LDS reads (stamps,
-// DESIGN.md section 8) -- 0.8 us per step for 0.52 us of MFMA.  Here a compute wave owns 64 rows x 128 columns of the
-// tile (128 accumulator registers) and software-pipelines ITSELF: while the 32 MFMAs of one half K-step run, the 12
-// fragment reads of the next half K-step are in flight into a second register set, so the wave's stream is MFMAs with
-// LDS reads in their shadows and ONE barrier per K-step (in the middle: "everybody has read stage g; stage g+1 has
-// landed").  Producer waves (one per SIMD, asleep at the barrier most of the time) issue every LDS-DMA and do all the
-// waiting on memory.
-//   step g, first half:   ds_read (g, kk=1) -> set 1   ||  32 MFMAs on set 0 (g, kk=0)      | lgkmcnt(0) | barrier
-//   step g, second half:  ds_read (g+1, kk=0) -> set 0 ||  32 MFMAs on set 1 (g, kk=1)      | lgkmcnt(0)
-// Hazards (ring of 3 stages, K-step x in stage x % 3):
-//   RAW  stage g+1 is first read in the second half of step g, after barrier(g); every producer passed a counted vmcnt
-//        for its pieces of K-step g+1 before arriving at barrier(g).
-//   WAR  K-step g+3 is written into stage g % 3 after barrier(g); the last reads of stage g (kk=1) completed
-//        (lgkmcnt(0)) before the readers arrived at barrier(g).
-//   EPI 0: C = A.B^T       EPI 3: SwiGLU (B tile = 64 gate rows | 64 up rows: gate and up of one output in one lane)
-template <int EPI>
-__global__ __launch_bounds__(512) void gemm_p1_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B, bf16* C, int M,
-                                                      int N, int K, long lda, long ldb, long ldc, int tiles_m, int tiles_n,
-                                                      int group_m, EpiArgs ea) {
-  static_assert(EPI == 0 || EPI == 3, "plain or SwiGLU epilogue");
-  constexpr int BM = 256, NC = 4, NPROD = 4, NST = 3;
-  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;  // 48 KiB
-  constexpr int LOADS = (BM + BN) / (8 * NPROD);                                          // 12 pieces per producer and stage
-  constexpr int PATCH = 4096;                                                             // per compute wave: 16 rows x 256 B
-  __shared__ __attribute__((aligned(16))) char smem[NST * STAGE + NC * PATCH];            // 160 KiB
-  const int lane = lane_id();
-  const int w = wave_id_uniform();
-  const int ntiles = tiles_m * tiles_n;
-  const int nk = K / BK;
-  const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
-  const int total = my_tiles * nk;
-  auto origin = [&](int idx, int& tm, int& tn) __attribute__((always_inline)) {
-    const int t = xcd_remap((int)blockIdx.x + idx * (int)gridDim.x, ntiles);
-    tile_coords(t, tiles_m, tiles_n, group_m, tm, tn);
-  };
-
-  if (w >= NC) {  // ------------------------------------------------------------ producer waves: the operand stream
-    const int pw = w - NC;
-    FastStage<false, BM, NPROD> fa;
-    FastStage<false, BN, NPROD> fb;
-    fa.init(A, lda, 0, (unsigned)(((long)(M - 1) * lda + K) * 2), pw, lane);
-    fb.init(B, ldb, 0, (unsigned)(((long)(N - 1) * ldb + K) * 2), pw, lane, EPI == 3 ? ea.I - 64 : 0);
-    int pf_tile = 0, pf_k = 0;
-    unsigned pf_a = 0, pf_b = 0;
-    (void)pf_a; (void)pf_b;
-    auto pf_set = [&](int idx) __attribute__((always_inline)) {
-      int tm = 0, tn = 0;
-      if (idx < my_tiles) origin(idx, tm, tn);
-      pf_a = (unsigned)(((long)tm * BM) * lda * 2);
-      pf_b = (unsigned)(((long)tn * (EPI == 3 ? 64 : BN)) * ldb * 2);
-    };
-    auto pf_issue = [&](char* stage) __attribute__((always_inline)) {
-#if defined(__HIP_DEVICE_COMPILE__)
-      const int sa = (int)(pf_a + (unsigned)(pf_k * BK * 2));
-      const int sb = (int)(pf_b + (unsigned)(pf_k * BK * 2));
-#pragma unroll
-      for (int i = 0; i < FastStage<false, BM, NPROD>::NI; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(
-            fa.rsrc, (SD_LDS void*)(stage + (pw * FastStage<false, BM, NPROD>::NI + i) * 1024), 16, fa.voff[i], sa, 0, 0);
-#pragma unroll
-      for (int i = 0; i < FastStage<false, BN, NPROD>::NI; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(
-            fb.rsrc, (SD_LDS void*)(stage + A_BYTES + (pw * FastStage<false, BN, NPROD>::NI + i) * 1024), 16, fb.voff[i],
-            sb, 0, 0);
-#endif
-      if (++pf_k == nk) { pf_k = 0; pf_set(++pf_tile); }
-    };
-    pf_set(0);
-#pragma unroll
-    for (int d = 0; d < NST; ++d) pf_issue(smem + d * STAGE);  // K-steps 0, 1, 2 (steps past the end are never read)
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LOADS) : "memory");  // K-step 0 has landed
-    __builtin_amdgcn_s_barrier();                                     // B0
-    int nxt = 0;
-    for (int g = 0; g < total; ++g) {
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");  // K-step g+1 has landed (g+2 may be in flight)
-      __builtin_amdgcn_s_barrier();                                 // barrier(g): stage g % 3 is free
-      pf_issue(smem + nxt * STAGE);                                 // K-step g+3
-      nxt = (nxt == NST - 1) ? 0 : nxt + 1;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the tail prefetches before the workgroup retires
-    return;
-  }
-
-  // ---------------------------------------------------------------------------- compute waves (one per SIMD)
-  f32x4 acc[4][8];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  // fragment (i-th 16-row block of my 64 rows | j-th 16-column block) of half K-step kk: rows are multiples of 16 apart,
-  // so the XOR swizzle term (row & 7 = lane & 7) is the same for all of them: one per-lane base per kk, the rest constants
-  const int fr = lane & 15;
-  const unsigned base0 = (unsigned)(((fr * 8) + ((0 * 4 + (lane >> 4)) ^ (fr & 7))) << 4);
-  const unsigned base1 = (unsigned)(((fr * 8) + ((1 * 4 + (lane >> 4)) ^ (fr & 7))) << 4);
-  auto read_set = [&](const char* stage, unsigned base, bf16x8 (&fa_)[4], bf16x8 (&fb_)[8]) __attribute__((always_inline)) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) fa_[i] = *(const bf16x8*)(stage + base + (w * 64 + i * 16) * 128);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) fb_[j] = *(const bf16x8*)(stage + A_BYTES + base + (j * 16) * 128);
-  };
-  auto mma_set = [&](const bf16x8 (&fa_)[4], const bf16x8 (&fb_)[8]) __attribute__((always_inline)) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) acc[i][j] = mfma16(fb_[j], fa_[i], acc[i][j]);
-  };
-  bf16x8 a0[4], b0[8], a1[4], b1[8];
-  __builtin_amdgcn_s_barrier();  // B0: K-step 0 has landed
-  read_set(smem, base0, a0, b0);
-  // (the waits on LDS reads are the BUILTIN s_waitcnt, 0xC07F = lgkmcnt(0) alone: hipcc's own wait insertion sees it; an
-  // asm wait is invisible to it and it then drains the reads just issued in front of the first MFMA of the next half)
-  __builtin_amdgcn_s_waitcnt(0xC07F);
-  int cur_i = 0, ck = 0, ctile = 0;
-  char* ep = smem + NST * STAGE + w * PATCH;
-  for (int g = 0; g < total; ++g) {
-    const char* cur = smem + cur_i * STAGE;
-    const int nxt_i = (cur_i == NST - 1) ? 0 : cur_i + 1;
-    const char* nxs = smem + nxt_i * STAGE;
-    // ---- first half: reads of (g, kk=1) fly under the MFMAs of (g, kk=0)
-    read_set(cur, base1, a1, b1);
-    __builtin_amdgcn_s_setprio(1);
-    mma_set(a0, b0);
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();  // barrier(g)
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- second half: reads of (g+1, kk=0) fly under the MFMAs of (g, kk=1)
-    read_set(nxs, base0, a0, b0);
-    __builtin_amdgcn_s_setprio(1);
-    mma_set(a1, b1);
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-    __builtin_amdgcn_sched_barrier(0);
-    if (++ck == nk) {  // tile finished: this wave's 64 x 128 block leaves, clear, go on with the next tile
-      ck = 0;
-      int tm, tn;
-      origin(ctile++, tm, tn);
-      const int m0 = tm * BM;
-      const int r = lane & 15, q4 = lane >> 4;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int gm0 = m0 + w * 64 + i * 16;
-        if constexpr (EPI == 3) {
-          // act columns tn*64 .. +63: gate in acc[i][0..3], up in acc[i][4..7] (same lane, same output)
-          bf16x4 a4[4], g4[4], u4[4];
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const bf16 gb = (bf16)acc[i][j][e], ub = (bf16)acc[i][j + 4][e];
-              const float gf = (float)gb, uf = (float)ub;
-              g4[j][e] = gb; u4[j][e] = ub;
-              a4[j][e] = (bf16)(gf / (1.f + __expf(-gf)) * uf);
-            }
-          // three 16 x 64 images through the patch as whole 128-byte rows
-#pragma unroll
-          for (int which = 0; which < 3; ++which) {
-            if (which > 0 && !C) break;
-            const bf16x4(&o)[4] = which == 0 ? a4 : which == 1 ? g4 : u4;
-            bf16* dst = which == 0 ? ea.out2 : which == 1 ? C : C + ea.I;
-            const long ldd = which == 0 ? ea.ld2 : ldc;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) *(bf16x4*)(ep + r * 128 + (((2 * j + (q4 >> 1)) ^ (r & 7)) << 4) + (q4 & 1) * 8) = o[j];
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
-              const int rr = hh * 8 + (lane >> 3), cc = lane & 7;
-              const bf16x8 v = *(const bf16x8*)(ep + rr * 128 + ((cc ^ (rr & 7)) << 4));
-              const int gmr = gm0 + rr, gn = tn * 64 + cc * 8;
-              if (gmr < M && gn < ea.I) *(bf16x8*)(dst + (long)gmr * ldd + gn) = v;
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          }
-        } else {
-          // 16 rows x 128 columns = 16 rows x 256 B through the patch, stored as whole rows (4 rows per instruction)
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            bf16x4 o;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = (bf16)acc[i][j][e];
-            *(bf16x4*)(ep + r * 256 + (((2 * j + (q4 >> 1)) ^ (r & 15)) << 4) + (q4 & 1) * 8) = o;
-          }
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-          for (int hh = 0; hh < 4; ++hh) {
-            const int rr = hh * 4 + (lane >> 4), cc = lane & 15;
-            const bf16x8 v = *(const bf16x8*)(ep + rr * 256 + ((cc ^ (rr & 15)) << 4));
-            const int gmr = gm0 + rr, gn = tn * BN + cc * 8;
-            if (gmr < M && gn < N) *(bf16x8*)(C + (long)gmr * ldc + gn) = v;
-          }
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-      }
-    }
-    cur_i = nxt_i;
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------
 // Persistent 256 x 256 kernel for the forward (NT) GEMMs with many output columns: lm_head (N = vocabulary) and gate|up.
 // Every kernel above is bound by the L2 -> LDS rate (one CU's LDS-DMA sustains ~59 GB/s), i.e. by FLOP per staged
 // byte, i.e. by tile area: 256 x 128 stages (256+128)*2 B per 2*256*128 FLOP of a k (85 FLOP/B, 0.81 us per 64-deep
@@ -1566,423 +1363,6 @@ __global__ __launch_bounds__(768) void gemm_pgroup_tn_kernel(GroupArgs ga, int K
   if constexpr (SHARE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-// ---------------------------------------------------------------------------------------------------
-// Grouped persistent NT kernel: the SAME forward projection of the student and of the frozen teacher (they are
-// independent, have the same token count and run in lockstep: sd_qwen3_forward_pair) as ONE stream of work.  Alone, the
-// N = hidden projections of a 2048-token micro-batch have 64-128 tiles of 256x128 -- a quarter to a half of the CUs --
-// and every launch pays its own ramp; together, and optionally cut along K (a slice writes an fp32 slab that the
-// following RMSNorm sums: sd_rmsnorm_fwd_pair), they fill the chip with the big tile.  Same 12-wave structure, ring and
-// hazard argument as gemm_pstag_kernel; a workgroup's unit list is built per XCD so that every XCD gets an equal share of
-// EACH problem (the problems differ in K, i.e. in cost per unit) and, at any time, its 32 workgroups hold consecutive
-// units of one problem and one slice (shared operand panels in its L2).
-//   EPI 0: C (bf16) or, for nsplit > 1, slabs[slice] (fp32) = A . B^T
-//   EPI 3: SwiGLU as in gemm_pstag_kernel (B tile = 64 gate rows | 64 up rows), act -> out2, gate|up -> C when C != null
-struct NtGroupArgs {  // structure of arrays, indexed by a readfirstlane'd problem number (stays in kernarg memory)
-  const bf16* A[2];
-  const bf16* B[2];
-  bf16* C[2];
-  bf16* out2[2];
-  float* slabs[2];
-  long lda[2], ldb[2], ldc[2];
-  int M[2], N[2], K[2], I[2];                      // N: GEMM columns (2I for EPI 3)
-  int tiles_m[2], tiles_n[2], nsplit[2], kt_per[2];  // kt_per: K-steps of a slice (the last may be shorter)
-  int n;
-};
-
-// A problem field by (wave-uniform) problem number p in {0, 1}, as ARITHMETIC on the two values: a runtime index into
-// the argument struct, or a ?: that the optimiser may turn into a select of addresses, makes hipcc keep a copy of the
-// struct in scratch memory and read every field back from there.
-SD_DEV int psel_v(int p, int v0, int v1) { return v0 ^ ((v0 ^ v1) & -p); }
-SD_DEV long psel_v(int p, long v0, long v1) { return v0 ^ ((v0 ^ v1) & -(long)p); }
-template <class T> SD_DEV T* psel_v(int p, T* v0, T* v1) {
-  return (T*)(uintptr_t)psel_v(p, (long)(uintptr_t)v0, (long)(uintptr_t)v1);
-}
-#define PSEL(F) psel_v(p, ga.F[0], ga.F[1])
-template <int EPI>
-__global__ __launch_bounds__(768) void gemm_pgroup_nt_kernel(NtGroupArgs ga, int group_m) {
-  static_assert(EPI == 0 || EPI == 3, "plain / slab or SwiGLU epilogue");
-  constexpr int BM = 256, NW = 8, NPROD = 4, NST = 3, DEPTH = NST - 1;
-  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;  // 48 KiB
-  // the LDS-DMA issue is shared as in gemm_pstag_kernel: the producers stage B and the first half of A, every compute
-  // wave CW pieces of the second half of A in its LOAD phase (producers alone: ~1.05 us per K-step instead of 0.8)
-  constexpr int A_PIECES = BM / 8, B_PIECES = BN / 8;
-  constexpr int CW = (A_PIECES / 2) / NW;
-  constexpr int PA = (A_PIECES / 2) / NPROD, PB = B_PIECES / NPROD;
-  constexpr int LOADS = PA + PB;
-  constexpr int PATCH = 2048;
-  __shared__ __attribute__((aligned(16))) char smem[NST * STAGE + NW * PATCH];
-  const int lane = lane_id();
-  const int w = wave_id_uniform();
-  // ---- this workgroup's units: XCD x = blockIdx.x & 7 owns units [ubase_p(x), ubase_p(x) + ucnt_p(x)) of problem p; its
-  // wpx workgroups walk "problem 0's share, then problem 1's" with stride wpx
-  const int xcd = (int)blockIdx.x & 7, jx = (int)blockIdx.x >> 3, wpx = (int)gridDim.x >> 3;
-  const int ntile0 = ga.tiles_m[0] * ga.tiles_n[0], ntile1 = ga.n > 1 ? ga.tiles_m[1] * ga.tiles_n[1] : 0;
-  const int U0 = ntile0 * ga.nsplit[0], U1 = ga.n > 1 ? ntile1 * ga.nsplit[1] : 0;
-  const int ucnt0 = (U0 >> 3) + (xcd < (U0 & 7) ? 1 : 0), ucnt1 = (U1 >> 3) + (xcd < (U1 & 7) ? 1 : 0);
-  const int ubase0 = xcd * (U0 >> 3) + (xcd < (U0 & 7) ? xcd : (U0 & 7));
-  const int ubase1 = xcd * (U1 >> 3) + (xcd < (U1 & 7) ? xcd : (U1 & 7));
-  const int my_len = ucnt0 + ucnt1;
-  const int my_units = jx < my_len ? (my_len - jx + wpx - 1) / wpx : 0;
-  // unit idx of this workgroup -> problem, tile, K slice
-  auto locate = [&](int idx, int& p, int& tm, int& tn, int& slice, int& kt0, int& nk) __attribute__((always_inline)) {
-    const int s = jx + idx * wpx;
-    p = __builtin_amdgcn_readfirstlane(s < ucnt0 ? 0 : 1);
-    const int g = psel_v(p, ubase0 + s, ubase1 + (s - ucnt0));
-    const int nt = psel_v(p, ntile0, ntile1);
-    slice = g / nt;
-    const int tile = g - slice * nt;
-    tile_coords(tile, PSEL(tiles_m), PSEL(tiles_n), group_m < PSEL(tiles_m) ? group_m : PSEL(tiles_m), tm, tn);
-    const int kt_all = (PSEL(K) + BK - 1) / BK;
-    kt0 = slice * PSEL(kt_per);
-    const int kt1 = kt0 + PSEL(kt_per) < kt_all ? kt0 + PSEL(kt_per) : kt_all;
-    nk = kt1 - kt0;
-  };
-  int total = 0;
-  for (int i = 0; i < my_units; ++i) {
-    int p, tm, tn, sl, k0, nk;
-    locate(i, p, tm, tn, sl, k0, nk);
-    total += nk;
-  }
-  if (my_units == 0) return;  // (uniform per workgroup: no barrier has been executed yet)
-
-  if (w >= NW) {  // ------------------------------------------------------------ producer waves: the operand stream
-    const int pw = w - NW;
-    FastStage<false, BM, A_PIECES / PA> fa;  // NI = PA pieces: pieces pw*PA .. of the first half of the A tile
-    FastStage<false, BN, NPROD> fb;
-    static_assert(FastStage<false, BM, A_PIECES / PA>::NI == PA && FastStage<false, BN, NPROD>::NI == PB, "piece split");
-    int pf_idx = 0, pf_k = 0, pf_nk = 1;
-    unsigned pf_a = 0, pf_b = 0;
-    (void)pf_a; (void)pf_b;
-    auto pf_set = [&](int idx) __attribute__((always_inline)) {
-      int p, tm, tn, sl, k0, nk;
-      locate(idx < my_units ? idx : 0, p, tm, tn, sl, k0, nk);
-      fa.init(PSEL(A), PSEL(lda), 0, (unsigned)(((long)(PSEL(M) - 1) * PSEL(lda) + PSEL(K)) * 2), pw, lane, 0, pw * PA);
-      fb.init(PSEL(B), PSEL(ldb), 0, (unsigned)(((long)(PSEL(N) - 1) * PSEL(ldb) + PSEL(K)) * 2), pw, lane,
-              EPI == 3 ? PSEL(I) - 64 : 0);
-      const long m0 = (long)tm * BM, nb0 = (EPI == 3) ? (long)tn * 64 : (long)tn * BN;
-      pf_a = (unsigned)((m0 * PSEL(lda) + (long)k0 * BK) * 2);
-      pf_b = (unsigned)((nb0 * PSEL(ldb) + (long)k0 * BK) * 2);
-      pf_nk = nk;
-    };
-    auto pf_issue = [&](char* stage) __attribute__((always_inline)) {
-#if defined(__HIP_DEVICE_COMPILE__)
-      const int sa = (int)(pf_a + (unsigned)(pf_k * BK * 2));
-      const int sb = (int)(pf_b + (unsigned)(pf_k * BK * 2));
-#pragma unroll
-      for (int i = 0; i < PA; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(fa.rsrc, (SD_LDS void*)(stage + (pw * PA + i) * 1024), 16, fa.voff[i], sa, 0, 0);
-#pragma unroll
-      for (int i = 0; i < PB; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(fb.rsrc, (SD_LDS void*)(stage + A_BYTES + (pw * PB + i) * 1024), 16, fb.voff[i],
-                                                 sb, 0, 0);
-#endif
-      if (++pf_k == pf_nk) { pf_k = 0; pf_set(++pf_idx); }
-    };
-    pf_set(0);
-#pragma unroll
-    for (int d = 0; d < DEPTH; ++d) pf_issue(smem + d * STAGE);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    int nxt = DEPTH;
-    for (int g = 0; g < total; ++g) {
-      pf_issue(smem + nxt * STAGE);
-      nxt = (nxt == NST - 1) ? 0 : nxt + 1;
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DEPTH - 1) * LOADS) : "memory");
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_s_barrier();
-    }
-    __builtin_amdgcn_s_barrier();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    return;
-  }
-
-  // ---------------------------------------------------------------------------- compute waves
-  const int wm = w >> 1, wn = w & 1;
-  const int half = w >> 2;
-  f32x4 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  // this wave's share of the operand stream: CW pieces of the second half of every A stage, issued in LOAD(g) for K-step
-  // g+DEPTH and retired by a counted vmcnt before the barrier that closes the phase (same RAW / WAR argument as the
-  // producers'; a finished unit's stores sit in the same in-order counter)
-  FastStage<false, BM, A_PIECES / CW> fc;
-  static_assert(FastStage<false, BM, A_PIECES / CW>::NI == CW, "piece split");
-  int cf_idx = 0, cf_k = 0, cf_nk = 1;
-  unsigned cf_a = 0;
-  (void)cf_a;
-  auto cf_set = [&](int idx) __attribute__((always_inline)) {
-    int p, tm, tn, sl, k0, nk;
-    locate(idx < my_units ? idx : 0, p, tm, tn, sl, k0, nk);
-    fc.init(PSEL(A), PSEL(lda), 0, (unsigned)(((long)(PSEL(M) - 1) * PSEL(lda) + PSEL(K)) * 2), w, lane, 0,
-            A_PIECES / 2 + w * CW);
-    cf_a = (unsigned)((((long)tm * BM) * PSEL(lda) + (long)k0 * BK) * 2);
-    cf_nk = nk;
-  };
-  auto cf_issue = [&](char* stage) __attribute__((always_inline)) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    const int sa = (int)(cf_a + (unsigned)(cf_k * BK * 2));
-#pragma unroll
-    for (int i = 0; i < CW; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(fc.rsrc, (SD_LDS void*)(stage + (A_PIECES / 2 + w * CW + i) * 1024), 16,
-                                               fc.voff[i], sa, 0, 0);
-#endif
-    if (++cf_k == cf_nk) { cf_k = 0; cf_set(++cf_idx); }
-  };
-  cf_set(0);
-#pragma unroll
-  for (int d = 0; d < DEPTH; ++d) cf_issue(smem + d * STAGE);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  if (half == 1) __builtin_amdgcn_s_barrier();
-
-  int cur_i = 0, cnx_i = DEPTH, ck = 0, cunit = 0;
-  int cp, ctm, ctn, cslice, ckt0, cnk;
-  locate(0, cp, ctm, ctn, cslice, ckt0, cnk);
-  char* ep = smem + NST * STAGE + w * PATCH;
-  for (int g = 0; g < total; ++g) {
-    cf_issue(smem + cnx_i * STAGE);
-    cnx_i = (cnx_i == NST - 1) ? 0 : cnx_i + 1;
-    const char* cur = smem + cur_i * STAGE;
-    bf16x8 af[2][4], bfr[2][4];
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) af[kk][i] = load_frag<false, BM>(cur, wm * 64 + i * 16, kk, lane);
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        bfr[kk][j] = load_frag<false, BN>(cur + A_BYTES, EPI == 3 ? (j >> 1) * 64 + wn * 32 + (j & 1) * 16 : wn * 64 + j * 16, kk, lane);
-    }
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DEPTH - 1) * CW) : "memory");  // my pieces of K-step g+1 have landed
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(bfr[kk][j], af[kk][i], acc[i][j]);
-    __builtin_amdgcn_s_setprio(0);
-    if (++ck == cnk) {  // unit finished: this wave's 64 x 64 block leaves
-      ck = 0;
-      const int p = cp;
-      const int M = PSEL(M), N = PSEL(N);
-      const long ldc = PSEL(ldc);
-      bf16* const C = PSEL(C);
-      const int m0 = ctm * BM;
-      const int r = lane & 15, q4 = lane >> 4;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int gm0 = m0 + wm * 64 + i * 16;
-        if constexpr (EPI == 3) {
-          const int gm = gm0 + r, I = PSEL(I);
-          bf16* const out2 = PSEL(out2);
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            const int gc = ctn * 64 + wn * 32 + j * 16 + q4 * 4;  // column of act; gate at gc, up at I + gc
-            bf16x4 a4, g4, u4;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              // same rounding as the unfused pair: gate|up are rounded to bf16 first (sd_swiglu_fwd reads them back)
-              const bf16 gb = (bf16)acc[i][j][e], ub = (bf16)acc[i][j + 2][e];
-              const float gf = (float)gb, uf = (float)ub;
-              g4[e] = gb; u4[e] = ub;
-              a4[e] = (bf16)(gf / (1.f + __expf(-gf)) * uf);
-            }
-            if (gm < M && gc < I) {
-              *(bf16x4*)(out2 + (long)gm * I + gc) = a4;
-              if (C) {
-                *(bf16x4*)(C + (long)gm * ldc + gc) = g4;
-                *(bf16x4*)(C + (long)gm * ldc + I + gc) = u4;
-              }
-            }
-          }
-        } else if (PSEL(slabs)) {
-          // K slice: fp32 partial sums straight from the accumulators (16 rows x 64-byte pieces per instruction; the
-          // pieces of a 128-byte line meet in L2)
-          const int gn0 = ctn * BN + wn * 64 + q4 * 4;
-          float* dst = PSEL(slabs) + ((long)cslice * M + gm0 + r) * N + gn0;
-          if (gm0 + r < M) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-              if (gn0 + j * 16 < N) *(f32x4*)(dst + j * 16) = acc[i][j];
-          }
-        } else {
-          const int gn0 = ctn * BN + wn * 64;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            bf16x4 o;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = (bf16)acc[i][j][e];
-            *(bf16x4*)(ep + r * 128 + (((2 * j + (q4 >> 1)) ^ (r & 7)) << 4) + (q4 & 1) * 8) = o;
-          }
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-          for (int hh = 0; hh < 2; ++hh) {
-            const int rr = hh * 8 + (lane >> 3), cc = lane & 7;
-            const bf16x8 v = *(const bf16x8*)(ep + rr * 128 + ((cc ^ (rr & 7)) << 4));
-            const int gmr = gm0 + rr, gn = gn0 + cc * 8;
-            if (gmr < M && gn < N) *(bf16x8*)(C + (long)gmr * ldc + gn) = v;
-          }
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-      }
-      if (++cunit < my_units) locate(cunit, cp, ctm, ctn, cslice, ckt0, cnk);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    cur_i = (cur_i == NST - 1) ? 0 : cur_i + 1;
-  }
-  if (half == 0) __builtin_amdgcn_s_barrier();
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain my tail prefetches before the workgroup retires
-}
-#undef PSEL
-
-// ---------------------------------------------------------------------------------------------------
-// K-split staggered 64x128x64 kernel (8 waves) for GEMMs with few output tiles and a long K (N = hidden: o / down
-// forward, every dX; 128-256 tiles of 64x128 on 256 CUs).  With one 4-wave workgroup per CU there is one wave per
-// SIMD and its DMA issue, LDS reads and MFMAs run back to back (~1 270 cycles per K-step for 256 cycles of MFMA).
-// Here both 4-wave halves work on the SAME C tile: half h takes the K-tiles kt0 + 2t + h through its own 3-stage
-// ring (2 x 3 x 24 KiB), the halves run one phase apart exactly as in gemm_stag_kernel (same hazard argument, per
-// half), and the two partial accumulators are added through LDS before the common epilogue (fixed order:
-// deterministic).
-template <bool TA, bool TB, int EPI>
-__global__ __launch_bounds__(512, 2) void gemm_ks_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B, bf16* C,
-                                                         const bf16* R, float* __restrict__ slabs, int M, int N, int K,
-                                                         long lda, long ldb, long ldc, long ldr, int tiles_m, int tiles_n,
-                                                         int k_tiles_per_split, int group_m, EpiArgs ea) {
-  constexpr int BM = 64, NWH = 4, NST = 3;
-  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;  // 24 KiB
-  constexpr int LOADS = (BM + BN) / (8 * NWH);                                            // 6 per wave per tile
-  __shared__ __attribute__((aligned(16))) char smem[2 * NST * STAGE];                     // 144 KiB
-  const int lane = lane_id();
-  const int w = wave_id_uniform();
-  const int half = w >> 2, wh = w & 3;  // waves 0-3 / 4-7: one of each per SIMD
-  const int wm = wh >> 1, wn = wh & 1;
-  int tile, slice;
-  tile_and_slice(tiles_m * tiles_n, tile, slice);
-  int tm, tn;
-  tile_coords(tile, tiles_m, tiles_n, group_m, tm, tn);
-  const int m0 = tm * BM, n0 = tn * BN;
-  char* ring = smem + half * (NST * STAGE);
-
-  EpiPre<EPI, 64, 512> pre;
-  epi_preload<EPI, 64, 512>(pre, R, ea, M, N, ldr, m0, n0, tn);
-
-  f32x4 acc[2][4];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int kt_all = (K + BK - 1) / BK;
-  const int kt0 = slice * k_tiles_per_split;
-  const int kt1 = min(kt_all, kt0 + k_tiles_per_split);
-  const int nk = kt1 - kt0;
-  const int nkh = (nk + 1) >> 1;      // iterations of both halves
-  const int mine = (nk - half + 1) >> 1;  // K-tiles this half really owns (half 1 has one fewer when nk is odd)
-  FastStage<TA, BM, NWH> fa;
-  FastStage<TB, BN, NWH> fb;
-  fa.init(A, lda, m0, (unsigned)((TA ? ((long)(K - 1) * lda + M) : ((long)(M - 1) * lda + K)) * 2), wh, lane);
-  fb.init(B, ldb, n0, (unsigned)((TB ? ((long)(K - 1) * ldb + N) : ((long)(N - 1) * ldb + K)) * 2), wh, lane);
-#pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    fa.issue((kt0 + 2 * s + half) * BK, ring + s * STAGE, wh);
-    fb.issue((kt0 + 2 * s + half) * BK, ring + s * STAGE + A_BYTES, wh);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-  if (half == 1) __builtin_amdgcn_s_barrier();  // second half runs one phase behind
-
-  int cur_i = 0, nxt_i = 2;
-  for (int t = 0; t < nkh; ++t) {
-    // ---- LOAD(t)
-    {
-      char* nxt = ring + nxt_i * STAGE;
-      fa.issue((kt0 + 2 * (t + 2) + half) * BK, nxt, wh);
-      fb.issue((kt0 + 2 * (t + 2) + half) * BK, nxt + A_BYTES, wh);
-    }
-    const char* cur = ring + cur_i * STAGE;
-    bf16x8 af[2][2], bfr[2][4];
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      if constexpr (TA) {
-        load_frags_tr<BM, 2>(cur, wm * 32, kk, lane, af[kk]);
-      } else {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) af[kk][i] = load_frag<TA, BM>(cur, wm * 32 + i * 16, kk, lane);
-      }
-      if constexpr (TB) {
-        load_frags_tr<BN, 4>(cur + A_BYTES, wn * 64, kk, lane, bfr[kk]);
-      } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) bfr[kk][j] = load_frag<TB, BN>(cur + A_BYTES, wn * 64 + j * 16, kk, lane);
-      }
-    }
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- COMPUTE(t): the tile past the end of an odd K range (half 1) holds foreign data and is skipped
-    if (t < mine) {
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(bfr[kk][j], af[kk][i], acc[i][j]);
-      __builtin_amdgcn_s_setprio(0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    cur_i = (cur_i == 2) ? 0 : cur_i + 1;
-    nxt_i = (nxt_i == 2) ? 0 : nxt_i + 1;
-  }
-  if (half == 0) __builtin_amdgcn_s_barrier();  // re-align the halves
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
-  // half 1 parks its partial sums in LDS, half 0 adds them (same lane -> same address) and stores the total
-  float* cs = (float*)smem;  // [64][128] fp32
-  if (half == 1) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int m = wm * 32 + i * 16 + (lane & 15);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int cidx = wn * 16 + j * 4 + (lane >> 4);
-        *(f32x4*)(cs + m * 128 + ((cidx ^ (m & 15)) << 2)) = acc[i][j];
-      }
-    }
-  }
-  __syncthreads();
-  if (half == 0) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int m = wm * 32 + i * 16 + (lane & 15);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int cidx = wn * 16 + j * 4 + (lane >> 4);
-        f32x4* p = (f32x4*)(cs + m * 128 + ((cidx ^ (m & 15)) << 2));
-        *p = acc[i][j] + *p;
-      }
-    }
-  }
-  __syncthreads();
-  write_out<EPI, 64, 512>(cs, C, pre, slabs, ea, M, N, ldc, m0, n0, tn, slice);
-}
-
 // C = sum_s slab[s] (+ R), fixed order
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slabs, bf16* C, const bf16* R, int M,
                                                             int N, long ldc, long ldr, int splits) {
@@ -2012,18 +1392,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 #ifdef SD_STAMPS
 void* g_stamp_buffer = nullptr;  // diagnostic build: device buffer for the phase stamps of gemm_pstag_kernel
 #endif
-bool g_no_fast_stage = false;  // tests / A-B measurements: force the checked staging path
-bool g_force_p1 = false;       // tests / A-B measurements: gemm_p1_kernel where gemm_pstag_kernel would run (nst | 0x200)
-bool g_force_p256_unpaired = false;  // tests / A-B measurements: the 32-deep-stage form of gemm_p256_kernel (nst | 0x400)
-int g_cu_budget = 0;           // workgroups a persistent grouped / weight-gradient launch may use (0 = every CU): sd_debug_cu_budget
-// SD_GEMM_CU_BUDGET (multi-GPU runs): the persistent kernels of the BACKWARD (grouped weight gradients, lm_head weight
+// Measurement switches live in g_sd_debug (sd_debug.h, set through include/sd_hip_debug.h); defaults = product behaviour.
+// gemm_cu_budget (multi-GPU runs): the persistent kernels of the BACKWARD (grouped weight gradients, lm_head weight
 // gradient) take one workgroup per CU for their whole duration; when RCCL's reduction kernels hold c CUs meanwhile, c
 // workgroups start only after others have finished and the launch takes up to twice as long (measured with
 // bench.py --experiment-cu-hog 16: +22 % / +70 %).  A budget of 256 - c keeps every workgroup resident from the start.
-static int cu_budget() {
-  static const int env = getenv("SD_GEMM_CU_BUDGET") ? atoi(getenv("SD_GEMM_CU_BUDGET")) : 0;
-  return g_cu_budget > 0 ? g_cu_budget : env;
-}
+static int cu_budget() { return g_sd_debug.gemm_cu_budget > 0 ? (g_sd_debug.gemm_cu_budget & ~7) : 0; }
 thread_local bool g_skip_reduce = false;  // set by sd_gemm_bf16_splitk_partial around its dispatch
 
 template <int BM, int NST, bool TA, bool TB>
@@ -2032,7 +1406,7 @@ int launch(const void* A, const void* B, void* C, const void* R, float* slabs, i
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   const int kt_all = (K + BK - 1) / BK;
   const int per = (kt_all + splits - 1) / splits;
-  dim3 grid(tiles_m * tiles_n, splits), block((BM == 256 || (BM == 64 && NST == 9)) ? 512 : 256);
+  dim3 grid(tiles_m * tiles_n, splits), block(BM == 256 ? 512 : 256);
   // descriptor-based staging needs every k >= K to read as zero in at least one operand (transposed
   // operands get that from the hardware range check; two K-contiguous ones need K % 64 == 0) and 31-bit offsets
   const long bytes_a = (TA ? ((long)(K - 1) * lda + M) : ((long)(M - 1) * lda + K)) * 2;
@@ -2040,28 +1414,25 @@ int launch(const void* A, const void* B, void* C, const void* R, float* slabs, i
   const long span = ((long)kt_all + 6) * BK * 2 * (TA ? lda : 1) + bytes_a;
   const long span_b = ((long)kt_all + 6) * BK * 2 * (TB ? ldb : 1) + bytes_b;
   // persistent kernel: one workgroup per CU (a multiple of 8 so that every workgroup stays on its XCD's tile run)
-  static const int persist_grid = [] {
-    if (getenv("SD_GEMM_NO_PERSIST")) return 0;  // A/B measurements
+  static const int all_cus = [] {
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
       return 0;
     return cus & ~7;
   }();
-  static const bool p256_ok = !getenv("SD_GEMM_NO_P256");  // A/B measurements
-  static const bool p256_pair_env = !(getenv("SD_GEMM_P256_PAIR") && atoi(getenv("SD_GEMM_P256_PAIR")) == 0);  // A/B
-  const bool p256_pair = p256_pair_env && !g_force_p256_unpaired;
-  static const bool p1_env = getenv("SD_GEMM_P1") && atoi(getenv("SD_GEMM_P1")) != 0;  // A/B: one compute wave per SIMD
-  const bool use_p1 = p1_env || g_force_p1;
+  const int persist_grid = g_sd_debug.gemm_no_persist ? 0 : all_cus;
+  const bool p256_ok = !g_sd_debug.gemm_no_p256;
+  const bool p256_pair = !g_sd_debug.gemm_p256_unpaired;
   // Measured (tests/bench_p256.py, MI355X): the 256 x 256 kernel ties the 256 x 128 one on the lm_head class (544 vs
   // 557 us student, 924 vs 929 us teacher) and loses on gate|up (114 vs 93 us teacher, 37.6 vs 36.3 us student): both
   // settle at ~0.9 us per staged K-step whatever the bytes of the step, i.e. the loop is paced by the latency of the
   // operand stream at the LDS-limited prefetch depth, not by L2 -> LDS bandwidth per FLOP.  So only the vocabulary-wide
-  // GEMMs take it.  SD_GEMM_P256_MIN_TILES lowers the threshold for measurements / tests.
-  static const int p256_min_tiles = getenv("SD_GEMM_P256_MIN_TILES") ? atoi(getenv("SD_GEMM_P256_MIN_TILES")) : 1024;
-  static const int gm_env = getenv("SD_GEMM_GROUP_M") ? atoi(getenv("SD_GEMM_GROUP_M")) : 0;  // A/B measurements
+  // GEMMs take it.  gemm.p256_min_tiles (sd_hip_debug.h) lowers the threshold for measurements / tests.
+  const int p256_min_tiles = g_sd_debug.gemm_p256_min_tiles;
+  const int gm_env = g_sd_debug.gemm_group_m;
   int gm = gm_env > 0 ? gm_env : (BM == 256 ? 4 : 8);
   if (gm > tiles_m) gm = tiles_m;
-  const bool fast = !g_no_fast_stage && (TA || TB || (K % BK) == 0) && span < 0x7fffffffL && span_b < 0x7fffffffL;
+  const bool fast = !g_sd_debug.gemm_checked_staging && (TA || TB || (K % BK) == 0) && span < 0x7fffffffL && span_b < 0x7fffffffL;
 #ifdef SD_STAMPS
 #define SD_STAMP_ARGS() EpiArgs ea_st = ea; ea_st.cos_t = (const bf16*)g_stamp_buffer
 #define SD_STAMP_EA ea_st
@@ -2091,22 +1462,12 @@ int launch(const void* A, const void* B, void* C, const void* R, float* slabs, i
         break;                                                                                                         \
       }                                                                                                                \
     }                                                                                                                  \
-    if constexpr (BM == 256 && NST == 9 && !TA && !TB && (EPI == 0 || EPI == 3)) {                                   \
-      if (use_p1 && splits == 1 && !R && tiles_m * tiles_n > persist_grid && persist_grid > 0 && (K % BK) == 0 &&      \
-          (EPI != 3 || (ea.I % 64) == 0)) {                                                                            \
-        SD_PROF_LABEL("gemm_p1_kernel<%d>", EPI);                                                                      \
-        hipLaunchKernelGGL((gemm_p1_kernel<EPI>), dim3(persist_grid), dim3(512), 0, st, (const bf16*)A, (const bf16*)B, \
-                           (bf16*)C, M, N, K, lda, ldb, ldc, tiles_m, tiles_n, gm, ea);                                \
-        break;                                                                                                         \
-      }                                                                                                                \
-    }                                                                                                                  \
     if constexpr (BM == 256 && NST == 9 && (EPI == 0 || EPI == 3)) {                                                 \
       if (splits == 1 && tiles_m * tiles_n > persist_grid && persist_grid > 0) {                                       \
         SD_PROF_LABEL("gemm_pstag_kernel<4, %s, %s, %d>", TA ? "true" : "false", TB ? "true" : "false", EPI);          \
         SD_STAMP_ARGS();                                                                                               \
         /* weight gradients (TA): the backward's persistent launches honour the CU budget of a multi-GPU run */       \
-        const int pg = (TA && cu_budget() > 0 && (cu_budget() & ~7) > 0 && (cu_budget() & ~7) < persist_grid)          \
-                           ? (cu_budget() & ~7) : persist_grid;                                                        \
+        const int pg = (TA && cu_budget() > 0 && cu_budget() < persist_grid) ? cu_budget() : persist_grid;             \
         hipLaunchKernelGGL((gemm_pstag_kernel<4, TA, TB, EPI>), dim3(pg), dim3(768), 0, st, (const bf16*)A,            \
                            (const bf16*)B, (bf16*)C, (const bf16*)R, M, N, K, lda, ldb, ldc, ldr, tiles_m, tiles_n,    \
                            gm, SD_STAMP_EA);                                                                           \
@@ -2117,11 +1478,6 @@ int launch(const void* A, const void* B, void* C, const void* R, float* slabs, i
       SD_PROF_LABEL("gemm_stag_kernel<%s, %s, %d>", TA ? "true" : "false", TB ? "true" : "false", EPI);                \
       hipLaunchKernelGGL((gemm_stag_kernel<TA, TB, EPI>), grid, block, 0, st, (const bf16*)A, (const bf16*)B,          \
                          (bf16*)C, (const bf16*)R, slabs, M, N, K, lda, ldb, ldc, ldr, tiles_m, tiles_n, per, gm, ea); \
-    } else if constexpr (BM == 64 && NST == 9) {                                                                     \
-      SD_PROF_LABEL("gemm_ks_kernel<%s, %s, %d>", TA ? "true" : "false", TB ? "true" : "false", (EPI >= 3 ? 0 : EPI)); \
-      hipLaunchKernelGGL((gemm_ks_kernel<TA, TB, (EPI >= 3 ? 0 : EPI)>), grid, block, 0, st, (const bf16*)A,           \
-                         (const bf16*)B, (bf16*)C, (const bf16*)R, slabs, M, N, K, lda, ldb, ldc, ldr, tiles_m,        \
-                         tiles_n, per, gm, ea);                                                                      \
     } else if (fast || EPI >= 3) {                                                                                   \
       SD_PROF_LABEL("gemm_bf16_kernel<%d, %d, %s, %s, %d, true>", BM, (NST == 9 ? 3 : NST), TA ? "true" : "false",     \
                     TB ? "true" : "false", EPI);                                                                       \
@@ -2167,8 +1523,6 @@ int check_args(const void* A, const void* B, const void* C, const void* R, int M
   return 0;
 }
 
-// variant: 0 = heuristic, else (BM | NST << 8) forced (tuning / tests)
-int g_force_variant = 0;
 
 int dispatch(const void* A, const void* B, void* C, const void* R, float* slabs, int splits, int M, int N, int K,
              long lda, long ldb, long ldc, long ldr, int ta, int tb, hipStream_t st, int epi_kind = 0,
@@ -2190,17 +1544,17 @@ int dispatch(const void* A, const void* B, void* C, const void* R, float* slabs,
     else if (tiles128 >= 256) { bm = 128; nst = 3; }
     else { bm = 64; nst = 3; }
   } else {  // TN: dW = dY^T . X (two warm activations)
-    static const long tn_stag_min = getenv("SD_TN_STAG_MIN") ? atol(getenv("SD_TN_STAG_MIN")) : 1024;  // A/B measurements
+    const long tn_stag_min = g_sd_debug.gemm_tn_stag_min;
     if (tiles256 >= tn_stag_min) { bm = 256; nst = 9; }
     else if (tiles128 >= 320) { bm = 128; nst = 2; }
     else { bm = 64; nst = blocks64 <= 320 ? 3 : 2; }
   }
-  if (g_force_variant) { bm = g_force_variant & 0xffff; nst = g_force_variant >> 16; }
+  if (g_sd_debug.gemm_force_bm) { bm = g_sd_debug.gemm_force_bm; nst = g_sd_debug.gemm_force_nst; }
   // the staggered kernel only has the descriptor staging path
-  bool stag_ok = !g_no_fast_stage && (ta || tb || (K % BK) == 0) &&
+  bool stag_ok = !g_sd_debug.gemm_checked_staging && (ta || tb || (K % BK) == 0) &&
                        ((long)K * (ta ? lda : 1) + (long)M * (ta ? 1 : lda)) * 2 < 0x70000000L &&
                        ((long)K * (tb ? ldb : 1) + (long)N * (tb ? 1 : ldb)) * 2 < 0x70000000L;
-  if (nst == 9 && (!stag_ok || (bm != 256 && bm != 64) || (bm == 64 && epi_kind >= 3))) nst = 3;
+  if (nst == 9 && (!stag_ok || bm != 256)) nst = 3;
   SdProfScope prof(ta ? SD_K_GEMM_TN : (tb ? SD_K_GEMM_NN : ((bm == 256 && nst == 9) ? SD_K_GEMM_NT_STAG : SD_K_GEMM_NT)),
                    2.0 * M * N * K, st);
 #define SD_GO(BM_, NST_, TA_, TB_) \
@@ -2210,7 +1564,6 @@ int dispatch(const void* A, const void* B, void* C, const void* R, float* slabs,
     if (bm == 256 && nst == 9 && stag_ok) SD_GO(256, 9, TA_, TB_); \
     if (bm == 256 && nst == 2) SD_GO(256, 2, TA_, TB_);     \
     if (bm == 256) SD_GO(256, 3, TA_, TB_);                 \
-    if (bm == 64 && nst == 9) SD_GO(64, 9, TA_, TB_);       \
     if (bm == 64 && nst == 2) SD_GO(64, 2, TA_, TB_);       \
     if (bm == 64 && nst == 3) SD_GO(64, 3, TA_, TB_);       \
     if (bm == 64) SD_GO(64, 4, TA_, TB_);                   \
@@ -2238,16 +1591,6 @@ extern "C" int sd_gemm_bf16(const void* A, const void* B, void* C, const void* R
 extern "C" void sd_debug_stamp_buffer(void* p) { g_stamp_buffer = p; }
 #endif
 
-extern "C" void sd_debug_cu_budget(int cus) { g_cu_budget = cus; }
-
-extern "C" void sd_gemm_force_variant(int bm, int nst) {
-  g_no_fast_stage = (nst & 0x100) != 0;  // nst | 0x100: checked (pointer) staging instead of buffer descriptors
-  g_force_p1 = (nst & 0x200) != 0;       // nst | 0x200: the one-compute-wave-per-SIMD persistent kernel
-  g_force_p256_unpaired = (nst & 0x400) != 0;  // nst | 0x400: gemm_p256_kernel with 32-deep half-line stages
-  nst &= 0xff;
-  g_force_variant = bm ? (bm | (nst << 16)) : 0;
-}
-
 extern "C" int sd_gemm_splitk_plan(int M, int N, int K) {
   // The kernels are bound by the L2 -> LDS rate, i.e. by FLOP per staged byte, i.e. by tile area: a GEMM whose
   // output has fewer than 256 tiles of 256x128 is split along K so that it can still use those tiles.  Measured
@@ -2255,12 +1598,12 @@ extern "C" int sd_gemm_splitk_plan(int M, int N, int K) {
   // for the lm_head-class contraction (K = vocabulary, 8 slices); K <= 4096 is best unsplit on 64x128 tiles.
   const long tiles = (long)((M + 255) / 256) * ((N + BN - 1) / BN);
   const int kt = (K + BK - 1) / BK;
-  static const int min_kt = getenv("SD_SPLITK_MIN_KT") ? atoi(getenv("SD_SPLITK_MIN_KT")) : 96;  // A/B measurements
+  const int min_kt = g_sd_debug.gemm_splitk_min_kt;
   if (tiles >= 256 || kt < min_kt) return 1;
   // The slice count that fills whole rounds of 256 workgroups best (fewest slices on a tie: every slice is another
   // fp32 slab; a slice keeps at least 24 K-steps).  48 tiles (lm_head dX on R = 1536 rows) -> 5 slices = 240
   // workgroups, not 8 = 384 = 1.5 rounds; 64 tiles -> 4.
-  static const int min_slice = getenv("SD_SPLITK_MIN_SLICE") ? atoi(getenv("SD_SPLITK_MIN_SLICE")) : 24;  // A/B measurements
+  const int min_slice = g_sd_debug.gemm_splitk_min_slice < 1 ? 1 : g_sd_debug.gemm_splitk_min_slice;
   const int cmax = kt / min_slice < 8 ? kt / min_slice : 8;
   int s = 1;
   double best = (double)tiles / 256.0;
@@ -2332,64 +1675,16 @@ extern "C" int sd_gemm_grouped_tn(const sd_gemm_problem* probs, int n, int K, in
     return SD_ERR_UNSUPPORTED;
   cus &= ~7;
   if (cus <= 0) return SD_ERR_UNSUPPORTED;
-  if (cu_budget() > 0 && (cu_budget() & ~7) < cus && (cu_budget() & ~7) > 0) cus = cu_budget() & ~7;
+  if (cu_budget() > 0 && cu_budget() < cus) cus = cu_budget();
   SdProfScope prof(SD_K_GEMM_TN, flops, (hipStream_t)stream);
   SD_PROF_LABEL("gemm_pgroup_tn_kernel<%s>", accumulate ? "true" : "false");
-  // A/B (tests/bench_grouped.py, MI355X): sharing the DMA issue with the compute waves is 2-4 % SLOWER here (73.5-74.6 vs
-  // 76.3-78.3 us for a student layer's four weight gradients), unlike gemm_pstag_kernel's +3 %: off by default
-  static const bool share = getenv("SD_TN_SHARE") ? atoi(getenv("SD_TN_SHARE")) != 0 : false;
+  // (sharing the DMA issue with the compute waves, gemm_pstag_kernel's +3 %, was measured 2-4 % SLOWER here -- 73.5-74.6 vs
+  // 76.3-78.3 us for a student layer's four weight gradients -- so the producers issue every piece: SHARE = false)
   const dim3 grid(start < cus ? start : cus);
 #define SD_TN_GO(ACC, SH) hipLaunchKernelGGL((gemm_pgroup_tn_kernel<ACC, SH>), grid, dim3(768), 0, (hipStream_t)stream, ga, K, 4)
-  if (accumulate) { if (share) SD_TN_GO(true, true); else SD_TN_GO(true, false); }
-  else { if (share) SD_TN_GO(false, true); else SD_TN_GO(false, false); }
+  if (accumulate) SD_TN_GO(true, false);
+  else SD_TN_GO(false, false);
 #undef SD_TN_GO
-  SD_CHECK_LAUNCH();
-  return 0;
-}
-
-// The same forward projection of two models (or any two independent NT GEMMs) as ONE persistent launch, see
-// gemm_pgroup_nt_kernel.  probs[i].nsplit > 1: fp32 slabs instead of C.  swiglu: EPI 3 (N = 2I, act -> out2).
-extern "C" int sd_gemm_grouped_nt(const sd_gemm_nt_problem* probs, int n, int swiglu, void* stream) {
-  if (n <= 0 || n > 2 || !probs) return SD_ERR_SHAPE;
-  NtGroupArgs ga{};
-  double flops = 0.0;
-  for (int p = 0; p < n; ++p) {
-    const sd_gemm_nt_problem& q = probs[p];
-    if (q.M <= 0 || q.N <= 0 || q.K <= 0 || (q.K % BK) || (q.N & 7) || ((q.lda | q.ldb | q.ldc) & 7)) return SD_ERR_UNSUPPORTED;
-    if (((uintptr_t)q.A | (uintptr_t)q.B | (uintptr_t)q.C | (uintptr_t)q.out2 | (uintptr_t)q.slabs) & 15) return SD_ERR_ALIGN;
-    if (((long)q.M * q.lda + q.K) * 2 >= 0x70000000L || ((long)q.N * q.ldb + q.K) * 2 >= 0x70000000L) return SD_ERR_UNSUPPORTED;
-    const int nsplit = q.nsplit < 1 ? 1 : q.nsplit;
-    if (swiglu && (nsplit != 1 || (q.N & 1) || ((q.N / 2) % 64) || !q.out2)) return SD_ERR_UNSUPPORTED;
-    if (!swiglu && nsplit > 1 && !q.slabs) return SD_ERR_WORKSPACE;
-    if (!swiglu && nsplit == 1 && !q.C) return SD_ERR_SHAPE;
-    ga.A[p] = (const bf16*)q.A; ga.B[p] = (const bf16*)q.B; ga.C[p] = (bf16*)q.C; ga.out2[p] = (bf16*)q.out2;
-    ga.slabs[p] = nsplit > 1 ? q.slabs : nullptr;
-    ga.lda[p] = q.lda; ga.ldb[p] = q.ldb; ga.ldc[p] = q.ldc;
-    ga.M[p] = q.M; ga.N[p] = q.N; ga.K[p] = q.K; ga.I[p] = swiglu ? q.N / 2 : 0;
-    ga.tiles_m[p] = (q.M + 255) / 256;
-    ga.tiles_n[p] = swiglu ? (ga.I[p] + 63) / 64 : (q.N + BN - 1) / BN;
-    const int kt_all = q.K / BK;
-    if (nsplit > kt_all) return SD_ERR_SHAPE;
-    ga.nsplit[p] = nsplit;
-    ga.kt_per[p] = (kt_all + nsplit - 1) / nsplit;
-    if ((long)ga.kt_per[p] * (nsplit - 1) >= kt_all) return SD_ERR_SHAPE;  // an empty last slice
-    flops += 2.0 * q.M * q.N * q.K;
-  }
-  ga.n = n;
-  int dev = 0, cus = 0;
-  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-    return SD_ERR_UNSUPPORTED;
-  cus &= ~7;
-  if (cus <= 0) return SD_ERR_UNSUPPORTED;
-  // a multiple of 8 workgroups, at most one per CU and no more than the busiest XCD's share needs
-  long per_xcd = 0;
-  for (int p = 0; p < n; ++p) per_xcd += ((long)ga.tiles_m[p] * ga.tiles_n[p] * ga.nsplit[p] + 7) / 8;
-  if (g_cu_budget > 0 && (g_cu_budget & ~7) < cus) cus = g_cu_budget & ~7;
-  const int grid = (int)(per_xcd * 8 < cus ? per_xcd * 8 : cus);
-  SdProfScope prof(SD_K_GEMM_NT_STAG, flops, (hipStream_t)stream);
-  SD_PROF_LABEL("gemm_pgroup_nt_kernel<%d>", swiglu ? 3 : 0);
-  if (swiglu) hipLaunchKernelGGL(gemm_pgroup_nt_kernel<3>, dim3(grid), dim3(768), 0, (hipStream_t)stream, ga, 4);
-  else hipLaunchKernelGGL(gemm_pgroup_nt_kernel<0>, dim3(grid), dim3(768), 0, (hipStream_t)stream, ga, 4);
   SD_CHECK_LAUNCH();
   return 0;
 }

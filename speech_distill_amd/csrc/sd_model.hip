@@ -8,6 +8,7 @@
 #include <stdlib.h>
 #include "../../include/sd_hip.h"
 #include "sd_events.h"
+#include "sd_debug.h"
 
 namespace {
 
@@ -99,36 +100,14 @@ LayerActs layer_acts(const Sizes& s, char* base, int l, int save) {
   return a;
 }
 
-// K slices for an inference forward's o / down projection (N = hidden) whose fp32 slabs the FOLLOWING RMSNorm sums
-// (sd_gemm_grouped_nt + sd_rmsnorm_fwd_slabs).  OFF unless SD_FWD_KSPLIT=1.  Measured alone (tests/bench_proj_norm.py, GEMM +
-// norm, cold operands, M = 2048) it wins at hidden 2048 (128 tiles of 256x128: two slices fill the 256 CUs once): o 44.3
-// -> 41.7 us, down 82.8 -> 76.6 us (hidden 1024: 64 tiles, four slices lose 2-7 us to the slab traffic).  In the
-// distillation step, where the teacher runs BESIDE the student on a second stream, it loses: bench.py 20.56 / 20.48 ms
-// with it, 20.40 / 20.25 ms without (same box, alternating) -- the persistent 256-workgroup launch takes every CU for
-// its whole duration, the 128x128 launches it replaces leave gaps the other model's kernels fill.
-int fwd_ksplit(int M, int N, int K) {
-  const char* e = getenv("SD_FWD_KSPLIT");
-  if (!e || atoi(e) == 0) return 1;
-  const long tiles = (long)((M + 255) / 256) * ((N + 127) / 128);
-  if (tiles < 96 || tiles > 128 || (K % 64) || K / 64 < 24) return 1;
-  return 2;
-}
-
 // One decoder layer (HF modeling_qwen3.py:227-250): a.x_in -> x_out, every intermediate into `a`.  x_out == nullptr
 // stops after the SwiGLU (the backward's recompute does not need the layer output again); keep_gu: gate|up is kept
-// for the backward.  slabs (inference only, else nullptr): fp32 scratch for K-sliced o / down projections; *pending
-// in: the previous layer left its down projection as `*pending` slabs (residual: prev_x_mid) and this layer's first
-// norm sums them into a.x_in; out: the same for this layer's down projection (x_out not written yet).
+// for the backward.
 int layer_forward(const sd_qwen3_dims* d, const Sizes& s, const LayerActs& a, const sd_qwen3_layer& w, char* x_out,
                   bool keep_gu, const int32_t* kv_len, const void* cos_tab, const void* sin_tab, int B, int T,
-                  void* stream, float* slabs = nullptr, int* pending = nullptr, const char* prev_x_mid = nullptr) {
+                  void* stream) {
   const float scale = 0.08838834764831845f;  // 128^-1/2
-  if (pending && *pending > 1) {
-    RUN(sd_rmsnorm_fwd_slabs(slabs, *pending, prev_x_mid, w.ln1, a.x_in, a.xn1, (float*)a.rstd1, s.M, s.h, d->eps, stream));
-    *pending = 0;
-  } else {
-    RUN(sd_rmsnorm_fwd(a.x_in, w.ln1, a.xn1, (float*)a.rstd1, s.M, s.h, d->eps, stream));
-  }
+  RUN(sd_rmsnorm_fwd(a.x_in, w.ln1, a.xn1, (float*)a.rstd1, s.M, s.h, d->eps, stream));
   // q|k|v projection with q/k-norm + RoPE in the GEMM epilogue (one head = one 128-column tile)
   int rc = sd_gemm_qkv_rope(a.xn1, w.wqkv, a.qkv, a.qk, w.q_gain, w.k_gain, cos_tab, sin_tab, s.M, T, s.Hq, s.Hkv, s.h,
                             d->eps, stream);
@@ -140,24 +119,14 @@ int layer_forward(const sd_qwen3_dims* d, const Sizes& s, const LayerActs& a, co
   }
   RUN(sd_attn_fwd(a.qk, a.qk + (int64_t)s.QD * 2, a.qkv + (int64_t)(s.QD + s.KD) * 2, a.ao, (float*)a.lse, kv_len,
                   s.QK, s.QK, s.QKV, s.QD, B, T, s.Hq, s.Hkv, 128, scale, stream));
-  const int ns_o = slabs ? fwd_ksplit(s.M, s.h, s.QD) : 1;
-  rc = SD_ERR_UNSUPPORTED;
-  if (ns_o > 1) {
-    const sd_gemm_nt_problem pr = {a.ao, w.wo, nullptr, nullptr, slabs, s.QD, s.QD, s.h, s.M, s.h, s.QD, ns_o};
-    rc = sd_gemm_grouped_nt(&pr, 1, 0, stream);
-    if (rc == 0) RUN(sd_rmsnorm_fwd_slabs(slabs, ns_o, a.x_in, w.ln2, a.x_mid, a.xn2, (float*)a.rstd2, s.M, s.h, d->eps, stream));
-    else if (rc != SD_ERR_UNSUPPORTED) return rc;
-  }
-  if (rc == SD_ERR_UNSUPPORTED) {
-    RUN(sd_gemm_bf16(a.ao, w.wo, a.x_mid, a.x_in, s.M, s.h, s.QD, s.QD, s.QD, s.h, s.h, 0, 0, stream));
-    RUN(sd_rmsnorm_fwd(a.x_mid, w.ln2, a.xn2, (float*)a.rstd2, s.M, s.h, d->eps, stream));
-  }
+  RUN(sd_gemm_bf16(a.ao, w.wo, a.x_mid, a.x_in, s.M, s.h, s.QD, s.QD, s.QD, s.h, s.h, 0, 0, stream));
+  RUN(sd_rmsnorm_fwd(a.x_mid, w.ln2, a.xn2, (float*)a.rstd2, s.M, s.h, d->eps, stream));
   // gate|up projection: SwiGLU runs in the GEMM epilogue when gate|up need not be kept (no backward follows:
   // the frozen teacher).  With the 2*I-wide store as well the fused epilogue is no faster than the separate
   // elementwise pass (tests/bench_fused.py), so the student keeps the two-kernel form.
-  static const int fuse_student = getenv("SD_FUSE_STUDENT_SWIGLU") ? atoi(getenv("SD_FUSE_STUDENT_SWIGLU")) : 0;  // A/B
-  rc = (keep_gu && !fuse_student) ? SD_ERR_UNSUPPORTED
-                                  : sd_gemm_swiglu(a.xn2, w.wgu, keep_gu ? a.gu : nullptr, a.act, s.M, s.I, s.h, stream);
+  rc = (keep_gu && !g_sd_debug.model_fuse_student_swiglu)
+           ? SD_ERR_UNSUPPORTED
+           : sd_gemm_swiglu(a.xn2, w.wgu, keep_gu ? a.gu : nullptr, a.act, s.M, s.I, s.h, stream);
   if (rc == SD_ERR_UNSUPPORTED) {
     RUN(sd_gemm_bf16(a.xn2, w.wgu, a.gu, nullptr, s.M, 2 * s.I, s.h, s.h, s.h, 2 * s.I, 0, 0, 0, stream));
     RUN(sd_swiglu_fwd(a.gu, a.act, s.M, s.I, stream));
@@ -165,16 +134,6 @@ int layer_forward(const sd_qwen3_dims* d, const Sizes& s, const LayerActs& a, co
     return rc;
   }
   if (!x_out) return 0;
-  const int ns_d = (slabs && pending) ? fwd_ksplit(s.M, s.h, s.I) : 1;
-  if (ns_d > 1) {
-    const sd_gemm_nt_problem pr = {a.act, w.wdown, nullptr, nullptr, slabs, s.I, s.I, s.h, s.M, s.h, s.I, ns_d};
-    rc = sd_gemm_grouped_nt(&pr, 1, 0, stream);
-    if (rc == 0) {
-      *pending = ns_d;  // the next norm (layer l+1's first, or the final one) adds a.x_mid and writes x_out
-      return 0;
-    }
-    if (rc != SD_ERR_UNSUPPORTED) return rc;
-  }
   RUN(sd_gemm_bf16(a.act, w.wdown, x_out, a.x_mid, s.M, s.h, s.I, s.I, s.I, s.h, s.h, 0, 0, stream));
   return 0;
 }
@@ -254,26 +213,16 @@ extern "C" int sd_qwen3_forward_rows(const sd_qwen3_dims* d, const sd_qwen3_para
 
   char* x_cur = save ? layer_acts(s, base, 0, save).x_in : base;
   RUN(sd_embedding_fwd(ids, p->embed, x_cur, s.M, s.h, s.V, stream));
-  // Inference (the frozen teacher): the gate|up buffer is idle whenever a projection's slabs are alive (the fused SwiGLU
-  // GEMM never writes it; the two-kernel fallback uses it between the o slabs' consumer and the down slabs' producer),
-  // and 2 slabs [M, h] fp32 fit in it (8 h <= 4 I).
-  float* slabs = (save == SD_SAVE_NONE && (int64_t)2 * s.M * s.h * 4 <= s.gu) ? (float*)carve(s, base).gu : nullptr;
-  int pending = 0;
-  const char* prev_x_mid = carve(s, base).x_mid;  // inference: every layer uses the one work set
   for (int l = 0; l < s.L; ++l) {
     LayerActs a = save ? layer_acts(s, base, l, save) : carve(s, base);
     a.x_in = x_cur;
     char* x_out;
     if (save) x_out = (l + 1 < s.L) ? layer_acts(s, base, l + 1, save).x_in : x_last;
     else x_out = (l + 1 < s.L) ? ((x_cur == pong) ? base : pong) : x_last;
-    RUN(layer_forward(d, s, a, p->layers_host[l], x_out, save != SD_SAVE_NONE, kv_len, cos_tab, sin_tab, B, T, stream,
-                      slabs, slabs ? &pending : nullptr, prev_x_mid));
+    RUN(layer_forward(d, s, a, p->layers_host[l], x_out, save != SD_SAVE_NONE, kv_len, cos_tab, sin_tab, B, T, stream));
     x_cur = x_out;
   }
-  if (pending > 1)
-    RUN(sd_rmsnorm_fwd_slabs(slabs, pending, prev_x_mid, p->final_norm, x_last, xn_f, (float*)rstd_f, s.M, s.h, d->eps, stream));
-  else
-    RUN(sd_rmsnorm_fwd(x_last, p->final_norm, xn_f, (float*)rstd_f, s.M, s.h, d->eps, stream));
+  RUN(sd_rmsnorm_fwd(x_last, p->final_norm, xn_f, (float*)rstd_f, s.M, s.h, d->eps, stream));
   if (logits && head_rows) {
     // lm_head only for the rows the loss will read (HF computes all B*T rows, train.py:54-55; the rows whose shifted
     // label is -100 never reach the loss, distillation_loss.py:37-45)
@@ -319,8 +268,9 @@ extern "C" int sd_qwen3_backward_rows(const sd_qwen3_dims* d, const sd_qwen3_par
   char* xn_rows = xn_f + s.x;
   const int acc = (accumulate & SD_BWD_ACCUMULATE) ? 1 : 0;
 #define ACC(ptr) (acc ? (const void*)(ptr) : (const void*)nullptr)
-  // A/B switch for measurements: SD_OVERLAP_MASK bit0 lm_head dW, bit1 gain reduces, bit2 attention dQ, bit3 grouped per-layer dW, bit4 batched per-layer gain reduce (default all on)
-  static const int ovl = getenv("SD_OVERLAP_MASK") ? atoi(getenv("SD_OVERLAP_MASK")) : 31;
+  // A/B switch for measurements ("model.overlap_mask", sd_hip_debug.h): bit0 lm_head dW, bit1 gain reduces, bit2 attention
+  // dQ, bit3 grouped per-layer dW, bit4 batched per-layer gain reduce (default all on)
+  const int ovl = g_sd_debug.model_overlap_mask;
   hipStream_t s1 = (hipStream_t)stream, s2 = (hipStream_t)side_stream;
   SdEventLease lease;
   if (s2 && !(lease.set = sd_lease_events())) return SD_ERR_WORKSPACE;

@@ -11,6 +11,7 @@
 #include "sd_common.cuh"
 #include "../../include/sd_hip.h"
 #include "sd_prof.h"
+#include "sd_debug.h"
 
 namespace {
 
@@ -334,7 +335,7 @@ extern "C" int sd_logsoftmax_topk(const void* logits, void* top_v, void* top_i, 
   while (KP < K) KP <<= 1;
   hipStream_t st = (hipStream_t)stream;
   SdProfScope prof(SD_K_TOPK, (double)rows * V * (dtype == SD_DTYPE_BF16 ? 2 : 4), st);
-  static const int nt_env = getenv("SD_TOPK_NT") ? atoi(getenv("SD_TOPK_NT")) : 0;  // A/B measurements
+  const int nt_env = g_sd_debug.topk_nt;
   const int nt = (nt_env == 256 || nt_env == 512 || nt_env == 1024) ? nt_env : 512;
 #define SD_TOPK_GO(T_, NP_, NT_)                                                                                     \
   SD_PROF_LABEL("topk_kernel<%s, %d, %d>", sizeof(T_) == 2 ? "__bf16" : "float", NP_, NT_);                          \

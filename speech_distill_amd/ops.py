@@ -124,19 +124,6 @@ def rmsnorm_fwd(x, w, eps=1e-6):
     return y, rstd
 
 
-def rmsnorm_fwd_slabs(slabs, resid, w, eps=1e-6):
-    """x = bf16(resid + sum of the fp32 K-slice slabs [nsplit,M,H]); returns (x, RMSNorm(x) * w, rstd)."""
-    _need(resid, torch.bfloat16, "resid"), _need(w, torch.bfloat16, "w")
-    if not slabs.is_cuda or slabs.dtype != torch.float32 or not slabs.is_contiguous() or slabs.shape[1:] != resid.shape:
-        raise ValueError("slabs: contiguous fp32 GPU tensor [nsplit, M, H]")
-    M, H = resid.shape
-    x, y = torch.empty_like(resid), torch.empty_like(resid)
-    rstd = torch.empty(M, dtype=torch.float32, device=resid.device)
-    check(load_lib().sd_rmsnorm_fwd_slabs(slabs.data_ptr(), slabs.shape[0], resid.data_ptr(), w.data_ptr(), x.data_ptr(),
-                                          y.data_ptr(), rstd.data_ptr(), M, H, eps, _stream()), "sd_rmsnorm_fwd_slabs")
-    return x, y, rstd
-
-
 def rmsnorm_bwd(dy, x, w, rstd, dres=None, dw=None, accumulate=False):
     M, H = x.shape
     lib = load_lib()
@@ -321,37 +308,6 @@ def gemm_grouped_tn(pairs, accumulate_into=None):
                                b.shape[1])
     check(load_lib().sd_gemm_grouped_tn(C.cast(probs, C.c_void_p), n, K, int(accumulate_into is not None), _stream()),
           "sd_gemm_grouped_tn")
-    return outs
-
-
-def gemm_grouped_nt(problems, swiglu=False):
-    """[(x [M,K], w [N,K], nsplit), ...] (at most 2) -> y_p = x_p @ w_p^T in ONE persistent launch (sd_gemm_grouped_nt).
-    nsplit > 1: the result comes back as fp32 slabs [nsplit, M, N] (un-reduced K slices) instead of a bf16 matrix.
-    swiglu: w_p = [gate rows | up rows] [2I,K]; returns (act [M,I], gate|up [M,2I]) per problem."""
-    from ._lib import GemmNtProblem
-    n = len(problems)
-    arr = (GemmNtProblem * n)()
-    outs = []
-    for i, (x, w, nsplit) in enumerate(problems):
-        _need(x, torch.bfloat16, "x"), _need(w, torch.bfloat16, "w")
-        M, K = x.shape
-        N = w.shape[0]
-        if w.shape[1] != K:
-            raise ValueError("gemm_grouped_nt: contraction mismatch")
-        c = out2 = slabs = None
-        if swiglu:
-            c = torch.empty(M, N, dtype=torch.bfloat16, device=x.device)
-            out2 = torch.empty(M, N // 2, dtype=torch.bfloat16, device=x.device)
-            outs.append((out2, c))
-        elif nsplit > 1:
-            slabs = torch.empty(nsplit, M, N, dtype=torch.float32, device=x.device)
-            outs.append(slabs)
-        else:
-            c = torch.empty(M, N, dtype=torch.bfloat16, device=x.device)
-            outs.append(c)
-        arr[i] = GemmNtProblem(x.data_ptr(), w.data_ptr(), _p(c), _p(out2), _p(slabs), x.stride(0), w.stride(0), N, M, N, K,
-                               int(nsplit))
-    check(load_lib().sd_gemm_grouped_nt(C.cast(arr, C.c_void_p), n, int(swiglu), _stream()), "sd_gemm_grouped_nt")
     return outs
 
 

@@ -34,11 +34,11 @@ def main():
         q, k, v = qkv[:, :Hq * 128], qkv[:, Hq * 128:(Hq + Hkv) * 128], qkv[:, (Hq + Hkv) * 128:]
         res = {}
         for name, variant in (("pipe", 2), ("classic", 1), ("pipe", 2), ("classic", 1)):
-            lib.sd_attn_force_variant(variant)
+            _lib.debug_set("attn.variant", variant)
             o, lse = ops.attn_fwd(q, k, v, B, T, Hq, Hkv)
             t = timeit(lambda: ops.attn_fwd(q, k, v, B, T, Hq, Hkv))
             res.setdefault(name, []).append((t, o, lse))
-        lib.sd_attn_force_variant(0)
+        _lib.debug_set("attn.variant", 0)
         same = torch.equal(res["pipe"][0][1], res["classic"][0][1]) and torch.equal(res["pipe"][0][2], res["classic"][0][2])
         fl = 2.0 * B * Hq * T * T * 128
         tp = min(x[0] for x in res["pipe"])

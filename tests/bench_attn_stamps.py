@@ -22,7 +22,7 @@ def main():
     buf = torch.zeros(8 * 256, dtype=torch.int64, device=dev)
     Hq, Hkv = 16, 8
     for variant, B, T in ((2, 4, 512), (1, 4, 512), (2, 1, 2048), (1, 1, 2048)):
-        lib.sd_attn_force_variant(variant)
+        _lib.debug_set("attn.variant", variant)
         M = B * T
         qkv = torch.randn(M, (Hq + 2 * Hkv) * 128, device=dev).bfloat16()
         q, k, v = qkv[:, :Hq * 128], qkv[:, Hq * 128:(Hq + Hkv) * 128], qkv[:, (Hq + Hkv) * 128:]

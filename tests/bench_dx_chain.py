@@ -6,7 +6,7 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from speech_distill_amd import ops  # noqa: E402
+from speech_distill_amd import _lib, ops  # noqa: E402
 from bench_pair import timeit  # noqa: E402
 
 dev = torch.device("cuda:0")
@@ -30,10 +30,10 @@ cases = (("down dX + SwiGLU bwd (N=3072, K=1024)", 2.0 * M * I * h, lambda: ops.
          ("qkv dX (N=1024, K=4096)", 2.0 * M * h * QKV, lambda: ops.gemm(dqkv, wqkv, False, True)))
 for name, fl, fn in cases:
     for bm, nst in ((0, 0), (64, 3), (64, 4), (128, 3), (128, 4), (256, 9)):
-        lib.sd_gemm_force_variant(bm, nst)
+        _lib.gemm_force_variant(bm, nst)
         try:
             t = timeit(fn, flush=flush)
             print(f"{name:40s} variant {bm or 'auto'}/{nst or ''}: {t:6.1f} us  {fl / t / 1e6:6.0f} TF/s", flush=True)
         except Exception as e:
             print(f"{name:40s} variant {bm}/{nst}: {type(e).__name__}", flush=True)
-    lib.sd_gemm_force_variant(0, 0)
+    _lib.gemm_force_variant(0, 0)

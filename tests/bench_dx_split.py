@@ -8,7 +8,7 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from speech_distill_amd import ops  # noqa: E402
+from speech_distill_amd import _lib, ops  # noqa: E402
 
 dev = torch.device("cuda:0")
 lib = ops.load_lib()
@@ -41,7 +41,7 @@ def main():
         ws = torch.empty(nb, dtype=torch.uint8, device=dev)
         out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
         for bm, nst in ((0, 0), (64, 3), (128, 3), (256, 9)):
-            lib.sd_gemm_force_variant(bm, nst)
+            _lib.gemm_force_variant(bm, nst)
             nsp = C.c_int(0)
 
             def gemm():
@@ -55,7 +55,7 @@ def main():
                 continue
             print(f"{name:16s} K={K} plan={plan} variant {bm or 'auto'}/{nst or ''}: nsplit={nsp.value} {t:6.1f} us  "
                   f"{2.0 * M * N * K / t / 1e6:6.0f} TF/s", flush=True)
-        lib.sd_gemm_force_variant(0, 0)
+        _lib.gemm_force_variant(0, 0)
 
 
 if __name__ == "__main__":

@@ -7,7 +7,7 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from speech_distill_amd import ops  # noqa: E402
+from speech_distill_amd import _lib, ops  # noqa: E402
 from bench_pair import timeit  # noqa: E402
 
 dev = torch.device("cuda:0")
@@ -26,10 +26,10 @@ for name, M, K, N, sw in (("teacher lm_head", 1536, 2048, 159488, False), ("stud
     outs = {}
     for rnd in range(2):
         for tag, v in (("paired", 0), ("half-line", 0x400)):
-            lib.sd_gemm_force_variant(0, v)
+            _lib.gemm_force_variant(0, v)
             outs[tag] = f()
             res.setdefault(tag, []).append(timeit(f, iters=10, warm=2, flush=flush))
-    lib.sd_gemm_force_variant(0, 0)
+    _lib.gemm_force_variant(0, 0)
     same = torch.equal(outs["paired"], outs["half-line"])
     p, h = min(res["paired"]), min(res["half-line"])
     print(f"{name:28s} identical={same}  paired {p:7.1f} us ({fl / p / 1e6:5.0f} TF/s)   half-line stages {h:7.1f} us "

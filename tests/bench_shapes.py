@@ -7,7 +7,7 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from speech_distill_amd import ops  # noqa: E402
+from speech_distill_amd import _lib, ops  # noqa: E402
 
 dev = torch.device("cuda:0")
 
@@ -57,14 +57,14 @@ def main():
         line = f"{name:26s} M={m:6d} N={n:6d} K={k:6d} "
         for bm, nst in variants:
             for use_sk in ([False, True] if ("--tune" in sys.argv and k >= 2048 and (m // 64) * (n // 128) < 512) else [sk]):
-                lib.sd_gemm_force_variant(bm, nst)
+                _lib.gemm_force_variant(bm, nst)
                 us = timeit(lambda: run(use_sk), iters=8 if n > 100000 or k > 100000 else 25)
                 tf = 2.0 * m * n * k / us / 1e6
                 key = ("auto" if bm == 0 else f"{bm}x{nst & 0xff}" + ("chk" if nst & 0x100 else "")) + ("+sk" if use_sk else "")
                 row[key] = round(tf, 1)
                 row[key + "_us"] = round(us, 1)
                 line += f" {key}:{tf:6.0f}"
-        lib.sd_gemm_force_variant(0, 0)
+        _lib.gemm_force_variant(0, 0)
         out.append(row)
         print(line, flush=True)
         del a, b, c, bs

@@ -18,7 +18,7 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from speech_distill_amd import ops  # noqa: E402
+from speech_distill_amd import _lib, ops  # noqa: E402
 
 dev = torch.device("cuda:0")
 

@@ -83,3 +83,47 @@ def test_flop_counts_of_the_product_equal_the_survey_figures():
     for d, o in ((s, Q.STUDENT_06B), (t, Q.TEACHER_17B)):
         for T in (512, 2048):
             assert d.flops_per_token(T) == Q.flops_per_token(o, T)
+
+
+def test_debug_interface_is_separate_documented_and_complete():
+    """include/sd_hip_debug.h: the measurement switches are NOT declared in sd_hip.h, the library never
+    reads the environment (no getenv in csrc/), every key the library knows is documented in the debug header, unknown
+    keys are refused, `reset` restores the defaults, and the split-K slice floor cannot be set to a divisor of zero."""
+    import speech_distill_amd as sda
+    from speech_distill_amd import _lib
+    prod = open(os.path.join(ROOT, "include", "sd_hip.h")).read()
+    code = re.sub(r"/\*.*?\*/", "", prod, flags=re.S)
+    assert "sd_debug" not in code and "force_variant" not in code and "cu_budget" not in code
+    for f in os.listdir(os.path.join(ROOT, "speech_distill_amd", "csrc")):
+        if f.endswith((".hip", ".h", ".cuh")):
+            assert "getenv" not in open(os.path.join(ROOT, "speech_distill_amd", "csrc", f)).read(), f
+    dbg = open(os.path.join(ROOT, "include", "sd_hip_debug.h")).read()
+    declared = set(re.findall(r"\b(sd_debug_[a-z_]+)\s*\(", re.sub(r"/\*.*?\*/", "", dbg, flags=re.S)))
+    assert declared == set(_lib.DEBUG_PROTOTYPES) == {"sd_debug_set", "sd_debug_get", "sd_debug_keys"}
+    lib = sda.load_lib()
+    n = lib.sd_debug_keys(None, 0)
+    buf = ctypes.create_string_buffer(n)
+    assert lib.sd_debug_keys(buf, n) == n
+    keys = buf.value.decode().split()
+    assert len(keys) >= 15
+    for k in keys:
+        assert re.search(r"^ \*\s+(\S+ / )?" + re.escape(k) + r"\b|" + re.escape(k.split(".")[0] + ".") + r"\S* / " +
+                         re.escape(k.split(".")[1]), dbg, re.M), f"{k} is not documented in sd_hip_debug.h"
+    assert lib.sd_debug_set(b"no.such.key", 1) == -3 and lib.sd_debug_get(b"no.such.key") == -2 ** 63
+    try:
+        _lib.debug_set("gemm.splitk_min_slice", 0)
+        assert _lib.debug_get("gemm.splitk_min_slice") == 1
+        assert lib.sd_gemm_splitk_plan(2048, 1024, 159488) >= 1
+        _lib.debug_set("gemm.cu_budget", 5)
+        assert _lib.debug_get("gemm.cu_budget") == 5
+    finally:
+        _lib.debug_set("reset", 0)
+    assert _lib.debug_get("gemm.cu_budget") == 0 and _lib.debug_get("gemm.splitk_min_slice") == 24
+
+
+def test_library_holds_no_undispatched_gemm_kernels():
+    """The experiment kernels of round 3 (gemm_p1, gemm_pgroup_nt, gemm_ks, rmsnorm_fwd_slabs) are out of the product."""
+    import speech_distill_amd as sda
+    blob = open(sda.lib_path(), "rb").read()
+    for dead in (b"gemm_p1_kernel", b"gemm_pgroup_nt_kernel", b"gemm_ks_kernel", b"rmsnorm_fwd_slabs_kernel"):
+        assert dead not in blob, dead

@@ -15,9 +15,6 @@ import torch
 from conftest import GOLDEN, load_golden
 
 pytestmark = pytest.mark.gpu
-# the 256x256 persistent GEMM serves only vocabulary-wide GEMMs by default; the tests reach it at small sizes
-# (read once, at the first GEMM launch of the process)
-os.environ.setdefault("SD_GEMM_P256_MIN_TILES", "150")
 
 
 @pytest.fixture(scope="module")
@@ -30,10 +27,14 @@ def O():
 def ops():
     import speech_distill_amd.ops as ops_
     ops_.load_lib()
-    return ops_
+    # the 256x256 persistent GEMM serves only vocabulary-wide GEMMs by default; the tests reach it at small sizes
+    _lib.debug_set("gemm.p256_min_tiles", 150)
+    yield ops_
+    _lib.debug_set("reset", 0)
 
 
 from gpu_util import bf, check_close, dev, record, to_dev  # noqa: E402
+from speech_distill_amd import _lib  # noqa: E402
 
 
 # ------------------------------------------------------------------------------------------- GEMM
@@ -86,21 +87,20 @@ def test_gemm_forced_variants_exact(ops, bm, nst, ta, tb):
     a = torch.randint(-3, 4, (K, M) if ta else (M, K), generator=g).float()
     b = torch.randint(-3, 4, (K, N) if tb else (N, K), generator=g).float()
     lib = ops.load_lib()
-    lib.sd_gemm_force_variant(bm, nst)
+    _lib.gemm_force_variant(bm, nst)
     try:
         got = ops.gemm(to_dev(bf(a)), to_dev(bf(b)), ta, tb).float().cpu()
     finally:
-        lib.sd_gemm_force_variant(0, 0)
+        _lib.gemm_force_variant(0, 0)
     # integer sums are exact in fp32; the bf16 output rounds values above 256 (RNE), so round the reference too
     assert torch.equal(got, _gemm_ref(a, b, ta, tb).float().bfloat16().float())
 
 
-@pytest.mark.parametrize("bm,K", [(256, 2112), (64, 2112), (64, 2048), (64, 64), (64, 192)])
+@pytest.mark.parametrize("bm,K", [(256, 2112), (256, 64), (256, 192)])
 @pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, True)])
 def test_gemm_staggered_kernel_random(ops, ta, tb, bm, K):
-    """the two-half staggered kernels (forced): 256x128 (halves split the rows) and 64x128 (halves split K; odd and
-    even numbers of K tiles, fewer tiles than ring stages), with a residual, long K so the 3-stage rings wrap many
-    times; run 3x (race screen)."""
+    """the two-half staggered 256x128 kernel (forced), with a residual: long K so the 3-stage ring wraps many times, and
+    fewer K tiles than ring stages; run 3x (race screen)."""
     g = torch.Generator().manual_seed(77)
     M, N = 1000, 520
     a = bf(torch.randn((K, M) if ta else (M, K), generator=g))
@@ -111,11 +111,11 @@ def test_gemm_staggered_kernel_random(ops, ta, tb, bm, K):
     ad, bd, rd = to_dev(a), to_dev(b), to_dev(r)
     outs = []
     for _ in range(3):
-        lib.sd_gemm_force_variant(bm, 9)
+        _lib.gemm_force_variant(bm, 9)
         try:
             outs.append(ops.gemm(ad, bd, ta, tb, residual=rd))
         finally:
-            lib.sd_gemm_force_variant(0, 0)
+            _lib.gemm_force_variant(0, 0)
     check_close(f"gemm_stag{bm}_K{K}_ta{int(ta)}tb{int(tb)}", outs[0], ref, 6e-3, 3e-3)
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
 
@@ -137,13 +137,13 @@ def test_gemm_fused_epilogues_equal_the_separate_kernels(ops, bm, nst):
     qk_ref = ops.qknorm_rope_fwd(qkv_ref, qg, kg, cos, sin, T, Hq, Hkv)
     gu_ref = ops.gemm(x, wgu)
     act_ref = ops.swiglu_fwd(gu_ref)
-    lib.sd_gemm_force_variant(bm, nst)
+    _lib.gemm_force_variant(bm, nst)
     try:
         qkv, qk = ops.gemm_qkv_rope(x, wqkv, qg, kg, cos, sin, T, Hq, Hkv)
         act, gu = ops.gemm_swiglu(x, wgu)
         act2, none = ops.gemm_swiglu(x, wgu, save_gu=False)
     finally:
-        lib.sd_gemm_force_variant(0, 0)
+        _lib.gemm_force_variant(0, 0)
     assert torch.equal(qkv, qkv_ref) and torch.equal(gu, gu_ref) and none is None
     assert torch.equal(qk, qk_ref), float((qk.float() - qk_ref.float()).abs().max())
     assert torch.equal(act, act_ref) and torch.equal(act2, act_ref), float((act.float() - act_ref.float()).abs().max())
@@ -163,82 +163,19 @@ def test_gemm_persistent_kernel(ops, ta, tb, K):
     lib = ops.load_lib()
     outs = []
     for _ in range(2):
-        lib.sd_gemm_force_variant(256, 9)
+        _lib.gemm_force_variant(256, 9)
         try:
             outs.append(ops.gemm(ad, bd, ta, tb))
         finally:
-            lib.sd_gemm_force_variant(0, 0)
-    lib.sd_gemm_force_variant(128, 3)
+            _lib.gemm_force_variant(0, 0)
+    _lib.gemm_force_variant(128, 3)
     try:
         other = ops.gemm(ad, bd, ta, tb)
     finally:
-        lib.sd_gemm_force_variant(0, 0)
+        _lib.gemm_force_variant(0, 0)
     check_close(f"gemm_persist_K{K}_ta{int(ta)}tb{int(tb)}", outs[0], _gemm_ref(a.float(), b.float(), ta, tb), 6e-3, 3e-3)
     assert torch.equal(outs[0], outs[1])
     assert torch.equal(outs[0], other)
-
-
-@pytest.mark.parametrize("K", [64, 192, 1088])
-def test_gemm_one_wave_per_simd_kernel_is_bit_identical(ops, K):
-    """gemm_p1_kernel (4 compute waves, one per SIMD, fragments double-buffered in registers, one barrier per K-step; reached
-    with sd_gemm_force_variant(0, 0x200)) against the persistent staggered kernel it would replace: the same K order per
-    accumulator, so plain and SwiGLU outputs are bit-identical; exact on integer data against fp64."""
-    g = torch.Generator().manual_seed(K + 7)
-    M, I = 1000, 64 * 70   # 4 x 70 tiles of 256x128 > 256 workgroups: the persistent path; ragged M edge
-    lib = ops.load_lib()
-    x = torch.randint(-3, 4, (M, K), generator=g).float()
-    w = torch.randint(-3, 4, (2 * I, K), generator=g).float()
-    x[0] += 1.0
-    xd, wd = to_dev(bf(x)), to_dev(bf(w))
-    xr, wr = to_dev(bf(torch.randn(M, K, generator=g))), to_dev(bf(torch.randn(2 * I, K, generator=g) * 0.1))
-    try:
-        lib.sd_gemm_force_variant(256, 9)
-        ops.prof_begin()
-        ref_i, ref_r = ops.gemm(xd, wd), ops.gemm(xr, wr)
-        ref_a, ref_gu = ops.gemm_swiglu(xr, wr)
-        ops.prof_end()
-        base_syms = set(ops.prof_symbols())
-        lib.sd_gemm_force_variant(256, 9 | 0x200)
-        ops.prof_begin()
-        got_i, got_r = ops.gemm(xd, wd), ops.gemm(xr, wr)
-        got_a, got_gu = ops.gemm_swiglu(xr, wr)
-        got_a2, _ = ops.gemm_swiglu(xr, wr, save_gu=False)
-        ops.prof_end()
-        syms = set(ops.prof_symbols())
-    finally:
-        lib.sd_gemm_force_variant(0, 0)
-    assert any(s.startswith("gemm_p1_kernel<0>") for s in syms) and any(s.startswith("gemm_p1_kernel<3>") for s in syms), syms
-    assert not any(s.startswith("gemm_p1_kernel") for s in base_syms)
-    assert torch.equal(got_i.float().cpu(), (x.double() @ w.double().T).float().bfloat16().float())
-    assert torch.equal(got_i, ref_i) and torch.equal(got_r, ref_r)
-    assert torch.equal(got_a, ref_a) and torch.equal(got_gu, ref_gu) and torch.equal(got_a2, ref_a)
-
-
-def test_rmsnorm_fwd_slabs_equals_residual_gemm_then_norm(ops):
-    """sd_rmsnorm_fwd_slabs(K-slice slabs, residual) == [residual epilogue of the unsplit GEMM] + sd_rmsnorm_fwd: with one
-    slab the sums are the same fp32 numbers (bit-identical x, y, rstd); with K slices the fp32 sum is re-associated
-    (x within one bf16 step of the unsplit result, y / rstd accordingly)."""
-    g = torch.Generator().manual_seed(12)
-    M, N, K = 300, 1024, 1536
-    x = to_dev(bf(torch.randn(M, K, generator=g)))
-    w = to_dev(bf(torch.randn(N, K, generator=g) * 0.05))
-    r = to_dev(bf(torch.randn(M, N, generator=g)))
-    gain = to_dev(bf(1 + 0.2 * torch.randn(N, generator=g)))
-    x_ref = ops.gemm(x, w, residual=r)
-    y_ref, rstd_ref = ops.rmsnorm_fwd(x_ref, gain)
-    acc = (x.double() @ w.double().T)
-    one = acc.float().unsqueeze(0).contiguous()  # "one slab" = the exact fp32-rounded product
-    x1, y1, rstd1 = ops.rmsnorm_fwd_slabs(one, r, gain)
-    want_x = (acc.float() + r.float()).bfloat16()
-    assert torch.equal(x1, want_x)
-    y_w, rstd_w = ops.rmsnorm_fwd(want_x, gain)
-    assert torch.equal(y1, y_w) and torch.equal(rstd1, rstd_w)
-    for ns in (2, 3):
-        slabs = ops.gemm_grouped_nt([(x, w, ns)])[0]
-        xs, ys, rs = ops.rmsnorm_fwd_slabs(slabs, r, gain)
-        check_close(f"norm_slabs_x_{ns}", xs, x_ref, 8e-3, 2e-3)
-        check_close(f"norm_slabs_y_{ns}", ys, y_ref, 1.6e-2, 3e-3)
-        check_close(f"norm_slabs_rstd_{ns}", rs, rstd_ref, 2e-3)
 
 
 @pytest.mark.parametrize("K", [64, 192, 1088])
@@ -246,7 +183,7 @@ def test_gemm_persistent_256x256_kernel(ops, K):
     """Forward (NT) GEMMs with >= 150 tiles of 256x256 take gemm_p256_kernel (8 waves, 64x128 per wave): K of 2, 6 and 34
     32-deep steps per tile, ragged M and N edges, one K stream across tile boundaries; must equal the 128x128 kernel bit
     for bit (same accumulation order over k); run twice (race screen).  The default is the paired form (two slots of
-    64 KiB holding both 32-deep halves of whole 128-byte lines); sd_gemm_force_variant(0, 0x400) runs the 32-deep half-line
+    64 KiB holding both 32-deep halves of whole 128-byte lines); _lib.gemm_force_variant(0, 0x400) runs the 32-deep half-line
     stages of round 2: both are checked."""
     g = torch.Generator().manual_seed(100 + K)
     M, N = 1000, 256 * 60 + 40
@@ -258,16 +195,16 @@ def test_gemm_persistent_256x256_kernel(ops, K):
     outs = [ops.gemm(ad, bd), ops.gemm(ad, bd)]
     ops.prof_end()
     assert any(k.startswith("gemm_p256_kernel<0, true>") for k in ops.prof_symbols()), ops.prof_symbols()
-    lib.sd_gemm_force_variant(0, 0x400)
+    _lib.gemm_force_variant(0, 0x400)
     try:
         ops.prof_begin()
         outs.append(ops.gemm(ad, bd))
         ops.prof_end()
         assert any(k.startswith("gemm_p256_kernel<0, false>") for k in ops.prof_symbols()), ops.prof_symbols()
-        lib.sd_gemm_force_variant(128, 3)
+        _lib.gemm_force_variant(128, 3)
         other = ops.gemm(ad, bd)
     finally:
-        lib.sd_gemm_force_variant(0, 0)
+        _lib.gemm_force_variant(0, 0)
     assert torch.equal(outs[0], outs[2])
     check_close(f"gemm_p256_K{K}", outs[0], _gemm_ref(a.float(), b.float(), False, False), 6e-3, 3e-3)
     assert torch.equal(outs[0], outs[1])
@@ -282,18 +219,17 @@ def test_gemm_persistent_256x256_kernel(ops, K):
 
 def test_gemm_persistent_swiglu(ops):
     """gate|up GEMM + SwiGLU on the persistent 256x256 kernel (tile = 128 gate rows | 128 up rows): bit-identical to
-    GEMM + swiglu; and on the 256x128 persistent kernel (SD_GEMM_NO_P256 is an A/B switch read at first use, so that
-    form is covered by test_gemm_fused_epilogues_equal_the_separate_kernels at forced variants)."""
+    GEMM + swiglu; and on the 256x128 persistent kernel ("gemm.no_p256" = 1)."""
     g = torch.Generator().manual_seed(5)
     M, K, I = 1100, 192, 64 * 90
     x = to_dev(bf(torch.randn(M, K, generator=g)))
     wgu = to_dev(bf(torch.randn(2 * I, K, generator=g) * 0.1))
     lib = ops.load_lib()
-    lib.sd_gemm_force_variant(128, 3)
+    _lib.gemm_force_variant(128, 3)
     try:
         gu_ref = ops.gemm(x, wgu)
     finally:
-        lib.sd_gemm_force_variant(0, 0)
+        _lib.gemm_force_variant(0, 0)
     act_ref = ops.swiglu_fwd(gu_ref)
     ops.prof_begin()
     act, gu = ops.gemm_swiglu(x, wgu)
@@ -302,61 +238,15 @@ def test_gemm_persistent_swiglu(ops):
     act2, none = ops.gemm_swiglu(x, wgu, save_gu=False)
     assert torch.equal(gu, gu_ref) and none is None
     assert torch.equal(act, act_ref) and torch.equal(act2, act_ref)
-
-
-@pytest.mark.parametrize("shapes", [
-    [(300, 136, 128, 1), (300, 264, 64, 1)],            # ragged edges, different K and N per problem
-    [(2048, 1024, 1024, 1), (2048, 2048, 1024, 1)],     # o-projection pair shapes (K scaled down)
-    [(520, 256, 1536, 3), (520, 128, 768, 2)],          # K slices of unequal length (24 K-steps in 3, 12 in 2)
-    [(1000, 392, 640, 5)],                              # one problem, the last slice shorter
-])
-def test_gemm_grouped_nt_equals_separate_gemms(ops, shapes):
-    """sd_gemm_grouped_nt (two independent forward projections as ONE persistent launch, optional K slices into fp32
-    slabs) against sd_gemm_bf16 on each problem: unsplit -> the same accumulation order, bit-identical; K slices ->
-    exact on integer data, and the slab sum rounds to the separate GEMM's result within one bf16 step on random data."""
-    g = torch.Generator().manual_seed(len(shapes) * 1000 + shapes[0][0])
-    for integer in (True, False):
-        probs, refs = [], []
-        for (M, N, K, ns) in shapes:
-            if integer:
-                x = torch.randint(-3, 4, (M, K), generator=g).float()
-                w = torch.randint(-3, 4, (N, K), generator=g).float()
-                x[0] += 1.0
-            else:
-                x, w = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.1
-            x, w = to_dev(bf(x)), to_dev(bf(w))
-            probs.append((x, w, ns))
-            refs.append(ops.gemm(x, w))
-        outs = ops.gemm_grouped_nt(probs)
-        for (M, N, K, ns), got, ref in zip(shapes, outs, refs):
-            if ns == 1:
-                assert got.dtype == torch.bfloat16 and torch.equal(got, ref), (M, N, K, integer)
-            else:
-                assert got.shape == (ns, M, N) and got.dtype == torch.float32
-                tot = got.double().sum(0)
-                if integer:
-                    assert torch.equal(tot.float().bfloat16(), ref), (M, N, K)
-                    want = (probs[shapes.index((M, N, K, ns))][0].double() @ probs[shapes.index((M, N, K, ns))][1].double().T)
-                    assert torch.equal(tot, want)
-                else:
-                    check_close(f"grouped_nt_slabs_{M}x{N}x{K}/{ns}", tot, ref.double(), 8e-3, 3e-3)
-
-
-def test_gemm_grouped_nt_swiglu_pair(ops):
-    """The gate|up projections of two models + SwiGLU in one launch == sd_gemm_bf16 + sd_swiglu_fwd per model, bit for bit
-    (gate|up kept, as the student needs it for the backward)."""
-    g = torch.Generator().manual_seed(77)
-    probs, refs = [], []
-    for (M, K, I) in ((700, 256, 64 * 9), (700, 128, 64 * 5)):
-        x = to_dev(bf(torch.randn(M, K, generator=g)))
-        wgu = to_dev(bf(torch.randn(2 * I, K, generator=g) * 0.1))
-        gu = ops.gemm(x, wgu)
-        probs.append((x, wgu, 1))
-        refs.append((ops.swiglu_fwd(gu), gu))
-    for (act, gu), (act_ref, gu_ref) in zip(ops.gemm_grouped_nt(probs, swiglu=True), refs):
-        assert torch.equal(gu, gu_ref) and torch.equal(act, act_ref)
-    with pytest.raises(Exception):  # K must be a multiple of 64 (both operands K-contiguous: no zero fill past K)
-        ops.gemm_grouped_nt([(to_dev(bf(torch.randn(64, 72))), to_dev(bf(torch.randn(128, 72))), 1)])
+    _lib.debug_set("gemm.no_p256", 1)
+    try:
+        ops.prof_begin()
+        act3, gu3 = ops.gemm_swiglu(x, wgu)
+        ops.prof_end()
+    finally:
+        _lib.debug_set("gemm.no_p256", 0)
+    assert any(k.startswith("gemm_pstag_kernel<4, false, false, 3>") for k in ops.prof_symbols()), ops.prof_symbols()
+    assert torch.equal(act3, act_ref) and torch.equal(gu3, gu_ref)
 
 
 @pytest.mark.parametrize("bm,nst", [(0, 0), (64, 3), (128, 3), (256, 9)])
@@ -370,11 +260,11 @@ def test_gemm_swiglu_bwd_epilogue_equals_the_separate_kernels(ops, bm, nst):
     dact = ops.gemm(dy, wdown, False, True)
     ref = ops.swiglu_bwd(dact, gu)
     lib = ops.load_lib()
-    lib.sd_gemm_force_variant(bm, nst)
+    _lib.gemm_force_variant(bm, nst)
     try:
         got = ops.gemm_swiglu_bwd(dy, wdown, gu)
     finally:
-        lib.sd_gemm_force_variant(0, 0)
+        _lib.gemm_force_variant(0, 0)
     assert torch.equal(got, ref), float((got.float() - ref.float()).abs().max())
 
 
@@ -403,7 +293,7 @@ def test_gemm_grouped_tn_equals_separate_gemms(ops, K):
 
 @pytest.mark.parametrize("budget", [240, 64])
 def test_persistent_weight_gradient_kernels_under_a_cu_budget(ops, budget, monkeypatch):
-    """sd_debug_cu_budget (SD_GEMM_CU_BUDGET in a multi-GPU run): the backward's persistent launches -- the grouped
+    """sd_debug_set("gemm.cu_budget") (SD_GEMM_CU_BUDGET in a multi-GPU run): the backward's persistent launches -- the grouped
     weight gradients and the lm_head-class TN GEMM -- on fewer workgroups than CUs give the same results bit for bit
     (a workgroup just walks more tiles), also while idle workgroups hold CU slots beside them (tests/csrc/cu_hog.hip)."""
     import ctypes
@@ -422,7 +312,7 @@ def test_persistent_weight_gradient_kernels_under_a_cu_budget(ops, budget, monke
         hog = ctypes.CDLL(path)
         hog.cu_hog.restype, hog.cu_hog.argtypes = ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
     side = torch.cuda.Stream()
-    lib.sd_debug_cu_budget(budget)
+    _lib.debug_set("gemm.cu_budget", budget)
     try:
         for it in range(3):
             if hog is not None and it:
@@ -434,7 +324,7 @@ def test_persistent_weight_gradient_kernels_under_a_cu_budget(ops, budget, monke
                 assert torch.equal(got[i], ref[i]), (it, i)
             assert torch.equal(got_head, ref_head), it
     finally:
-        lib.sd_debug_cu_budget(0)
+        _lib.debug_set("gemm.cu_budget", 0)
 
 
 @pytest.mark.parametrize("M,T,Hq,H", [(2048, 512, 16, 1024), (300, 100, 2, 256)])
@@ -674,12 +564,12 @@ def test_attention_fwd_pipelined_equals_classic(ops, B, T, Hq, Hkv, pad):
     outs = []
     try:
         for variant in (2, 1):
-            lib.sd_attn_force_variant(variant)
+            _lib.debug_set("attn.variant", variant)
             o, lse = ops.attn_fwd(q, k, v, B, T, Hq, Hkv, kv_len)
             torch.cuda.synchronize()
             outs.append((o.clone(), lse.clone()))
     finally:
-        lib.sd_attn_force_variant(0)
+        _lib.debug_set("attn.variant", 0)
     assert torch.isfinite(outs[0][0].float()).all()
     assert torch.equal(outs[0][0], outs[1][0])
     assert torch.equal(outs[0][1], outs[1][1])
