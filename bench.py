@@ -130,6 +130,8 @@ def main():
                     help="MEASUREMENT ONLY (not the reported configuration): select the loss rows once instead of every "
                          "step -- an upper bound on what the per-step host read of the row count costs")
     ap.add_argument("--no-overlap", action="store_true", help="single stream everywhere (clean per-kernel profiles)")
+    ap.add_argument("--no-fold", action="store_true",
+                    help="A/B: the frozen teacher runs its RMSNorm launches instead of folding the gains into the weights")
     ap.add_argument("--experiment-cu-hog", type=int, default=0, metavar="N",
                     help="MEASUREMENT ONLY (not the reported configuration): N idle workgroups (256 threads, 128 registers "
                          "per lane: a communication kernel's footprint) hold a CU slot each during every backward, on a "
@@ -169,6 +171,7 @@ def main():
             if p.dim() == 1:
                 p.data.fill_(1.0)
     teacher.eval().requires_grad_(False)
+    teacher.fold_norm_gains = not args.no_fold
     loss_fn = sda.DistillationLoss(temperature=2.0, alpha=0.5, inplace_grad=True)
     reducer = (ddp.attach(student, layers_per_bucket=args.layers_per_bucket, algo=args.comm_algo,
                           rehearse_single_rank=args.force_dist) if multi else None)

@@ -87,6 +87,26 @@ int sd_gemm_qkv_rope(const void* x, const void* wqkv, void* qkv_out, void* qk_ou
                      const void* cos_tab, const void* sin_tab, int M, int T, int Hq, int Hkv, int K, float eps,
                      void* stream);
 
+/* ---- RMSNorm folded into the projection behind it (the FROZEN teacher, train.py:60-69 / 165-169: its weights never
+ * change, so HF:59-64's  y = g * (x * rstd)  followed by  y W^T  (HF:252-254, 81-83) is  rstd * (x (W diag g)^T):
+ * the gain is multiplied into the weight rows once at load and the row statistic is applied as a row scale in the
+ * consuming GEMM's epilogue.  The statistic travels as per-128-column-tile partial sums of squares, fp32 [M, H/128]
+ * (H % 512 == 0, H/128 <= 16), written by whoever produced the row and summed in a fixed order by the consumer:
+ *   sd_embedding_fwd_ssq  the lookup of sd_embedding_fwd + the partials of its rows (input of layer 0);
+ *   sd_gemm_bf16_ssq      C = A . B^T + R (the o / down projection with its residual, HF:304-323) + the partials of C;
+ *   sd_gemm_qkv_rope_rs   sd_gemm_qkv_rope on the UN-normalised x with wqkv = Wqkv diag(input_layernorm gain);
+ *   sd_gemm_swiglu_rs     sd_gemm_swiglu on the UN-normalised x with wgu = Wgu diag(post_attention_layernorm gain).
+ * Arithmetic differs from the unfolded path only in rounding: the gain meets the weight instead of the activation, and
+ * the normalised row is never rounded to bf16 (tolerance test: test_folded_teacher_forward_matches_unfolded). */
+int sd_embedding_fwd_ssq(const int64_t* ids, const void* E, void* x, float* ssq_out, int M, int H, int V, void* stream);
+int sd_gemm_bf16_ssq(const void* A, const void* B, void* C, const void* R, float* ssq_out, int M, int N, int K, int64_t lda,
+                     int64_t ldb, int64_t ldc, int64_t ldr, void* stream);
+int sd_gemm_qkv_rope_rs(const void* x, const void* wqkv, void* qkv_out, void* qk_out, const void* q_gain, const void* k_gain,
+                        const void* cos_tab, const void* sin_tab, const float* ssq, int M, int T, int Hq, int Hkv, int K,
+                        float eps, void* stream);
+int sd_gemm_swiglu_rs(const void* x, const void* wgu, void* gu_out, void* act_out, const float* ssq, float eps, int M, int I,
+                      int K, void* stream);
+
 /* ---- RMSNorm (HF:59-64).  rstd (fp32 [M], nullable in fwd) is saved for backward. */
 int sd_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int M, int H, float eps, void* stream);
 int64_t sd_rmsnorm_bwd_workspace_bytes(int M, int H);
@@ -235,10 +255,17 @@ typedef struct {
  *                         (train.py:204-208, modeling_qwen3.py decoder-layer checkpointing): only the residual stream
  *                         entering each layer + two layer work sets; the backward (SD_BWD_RECOMPUTE) runs a layer's
  *                         forward again right before its backward.  Same kernels on the same inputs, so the
- *                         gradients are bit-identical to SD_SAVE_ALL. */
+ *                         gradients are bit-identical to SD_SAVE_ALL.
+ *   SD_SAVE_NONE_FOLDED   inference with every decoder layer's two RMSNorm gains folded into the weights the caller passes:
+ *                         layers_host[l].wqkv = Wqkv diag(ln1), .wgu = Wgu diag(ln2) (bf16(W[n][k] * g[k]), done once at
+ *                         load); ln1 / ln2 are not read and no RMSNorm kernel runs except the final one (its consumer is
+ *                         the tied embedding table): 1 instead of 2 L + 1 norm launches per pass.  Only for dims with
+ *                         sd_qwen3_fold_supported(d) != 0; logits agree with SD_SAVE_NONE to bf16 rounding. */
 #define SD_SAVE_NONE 0
 #define SD_SAVE_ALL 1
 #define SD_SAVE_LAYER_INPUTS 2
+#define SD_SAVE_NONE_FOLDED 3
+int sd_qwen3_fold_supported(const sd_qwen3_dims* d);
 /* bytes of activation storage for `sd_qwen3_forward` in that mode (negative: SD_ERR_* for an unknown mode) */
 int64_t sd_qwen3_acts_bytes(const sd_qwen3_dims* d, int B, int T, int save_for_backward);
 int64_t sd_qwen3_bwd_scratch_bytes(const sd_qwen3_dims* d, int B, int T);

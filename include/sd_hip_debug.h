@@ -21,7 +21,6 @@
  *   model.fuse_student_swiglu  0        SwiGLU in the gate|up GEMM epilogue also when gate|up is kept for the backward
  *   model.overlap_mask         31       sd_qwen3_backward: bit0 lm_head dW, bit1 gain reduces, bit2 attention dQ on the side
  *                                       stream, bit3 grouped per-layer dW, bit4 one batched gain reduce per layer
- *   model.no_fold              0        inference forward with folded gains: launch the RMSNorm kernels anyway (A/B)
  *   topk.nt                    0        threads per row of topk_kernel (256|512|1024; 0 = 512)
  *   qk_bwd.blocks              512      workgroups of qknorm_rope_bwd_kernel
  *   attn.variant               0        bit0: forward without the in-wave software pipeline at any T; bit1: with it at any T

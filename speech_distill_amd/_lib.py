@@ -82,6 +82,11 @@ PROTOTYPES = {
     "sd_rmsnorm_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _vp]),
     "sd_gemm_swiglu": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "sd_gemm_qkv_rope": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
+    "sd_embedding_fwd_ssq": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "sd_gemm_bf16_ssq": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _i64, _i64, _vp]),
+    "sd_gemm_qkv_rope_rs": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
+    "sd_gemm_swiglu_rs": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _vp]),
+    "sd_qwen3_fold_supported": (_i, [C.POINTER(Dims)]),
     "sd_gemm_bf16_splitk_partial": (_i, [_vp, _vp, _vp, _i, _i, _i, _i64, _i64, _i64, _i, _i, _vp, _i64, _vp, _vp]),
     "sd_rmsnorm_bwd_slabs": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _vp, _vp, _vp]),
     "sd_rmsnorm_bwd2": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _vp, _vp, _vp]),

@@ -16,7 +16,6 @@ struct SdDebug {
   // sd_model.hip
   int model_fuse_student_swiglu = 0;
   int model_overlap_mask = 31;  // bit0 lm_head dW, bit1 gain reduces, bit2 attention dQ, bit3 grouped per-layer dW, bit4 batched gain reduce
-  int model_no_fold = 0;        // inference forward: run the RMSNorm launches even when folded weights were given
   // sd_topk.hip / sd_elementwise.hip / sd_attn.hip
   int topk_nt = 0;
   int qk_bwd_blocks = 512;

@@ -24,7 +24,6 @@ const Key kKeys[] = {
     {"gemm.splitk_min_slice", &SdDebug::gemm_splitk_min_slice},
     {"model.fuse_student_swiglu", &SdDebug::model_fuse_student_swiglu},
     {"model.overlap_mask", &SdDebug::model_overlap_mask},
-    {"model.no_fold", &SdDebug::model_no_fold},
     {"topk.nt", &SdDebug::topk_nt},
     {"qk_bwd.blocks", &SdDebug::qk_bwd_blocks},
     {"attn.variant", &SdDebug::attn_variant},

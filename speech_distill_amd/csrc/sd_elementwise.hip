@@ -386,6 +386,29 @@ __global__ __launch_bounds__(256) void embedding_fwd_kernel(const int64_t* __res
   for (int c = lane_id() * 8; c < H; c += 512) *(bf16x8*)(x + (long)row * H + c) = *(const bf16x8*)(E + id * H + c);
 }
 
+// The same lookup, leaving per row and 128-column tile the sum of squares of the row (fp32 [M, H/128]): the statistic of the
+// FIRST decoder layer's input norm when that norm is folded into the q|k|v projection (sd_gemm_qkv_rope_rs).  A lane's 8
+// columns of chunk i lie in tile (lane >> 4) + 4 i, so one 16-lane DPP row sum is one tile.
+__global__ __launch_bounds__(256) void embedding_fwd_ssq_kernel(const int64_t* __restrict__ ids, const bf16* __restrict__ E,
+                                                                bf16* __restrict__ x, float* __restrict__ ssq, int M, int H,
+                                                                int V) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  long id = ids[row];
+  id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+  const int lane = lane_id(), nt = H >> 7;
+  for (int i = 0; i * 512 < H; ++i) {  // H % 512 == 0: every lane is active in every trip (DPP needs the full row)
+    const int c = lane * 8 + i * 512;
+    const bf16x8 v = *(const bf16x8*)(E + id * H + c);
+    *(bf16x8*)(x + (long)row * H + c) = v;
+    float ss = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; ss += f * f; }
+    ss = row16_sum(ss);
+    if ((lane & 15) == 0) ssq[(long)row * nt + (lane >> 4) + 4 * i] = ss;
+  }
+}
+
 // dst[rows[i]] = src[i] for unique row indices (dst was zero-filled by the launcher).
 __global__ __launch_bounds__(256) void rows_scatter_kernel(const bf16* __restrict__ src, const int64_t* __restrict__ rows,
                                                            bf16* __restrict__ dst, int n, int M, int H) {
@@ -659,6 +682,17 @@ extern "C" int sd_embedding_fwd(const int64_t* ids, const void* E, void* x, int 
   if (M <= 0 || (H & 7)) return SD_ERR_SHAPE;
   SdProfScope prof(SD_K_EMBED, 4.0 * M * H, ST);
   hipLaunchKernelGGL(embedding_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, ST, ids, (const bf16*)E, (bf16*)x, M, H, V);
+  SD_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int sd_embedding_fwd_ssq(const int64_t* ids, const void* E, void* x, float* ssq_out, int M, int H, int V,
+                                    void* stream) {
+  if (M <= 0 || (H & 7) || !ssq_out) return SD_ERR_SHAPE;
+  if ((H % 512) || H / 128 > 16) return SD_ERR_UNSUPPORTED;
+  SdProfScope prof(SD_K_EMBED, 4.0 * M * H, ST);
+  hipLaunchKernelGGL(embedding_fwd_ssq_kernel, dim3((M + 3) / 4), dim3(256), 0, ST, ids, (const bf16*)E, (bf16*)x, ssq_out, M,
+                     H, V);
   SD_CHECK_LAUNCH();
   return 0;
 }

@@ -166,12 +166,22 @@ SD_DEV bf16x8 load_frag32(const char* tile, int row16_base, int lane) {  // 16 r
 //          head; raw q|k|v go to C, normalised + rotated q|k heads to out2 [M,(Hq+Hkv)*128].
 //   EPI 5 (down-projection dX GEMM + SwiGLU backward, HF:81-83 run backwards): the tile is d(act); g0 = gate|up of the
 //          forward [M,2I] (row stride ld2), out2 = d(gate|up) [M,2I]; d(act) itself is not stored.
+//   Folded RMSNorm (round 4; the frozen teacher, HF:59-64 + the projection behind it): the norm's gain is folded into the
+//   weight rows once at load (W' = W.diag(g)), so y = rstd (.) (x W'^T) and the norm needs no pass of its own:
+//     ssq_out (EPI 1): the residual epilogue also leaves, per row and 128-column tile, the sum of squares of the bf16
+//             values it stores: ssq_out[row * ssq_n + tile] (fp32; ssq_n = N / 128 <= 16);
+//     ssq_in  (EPI 3 / 4): the consumer sums a row's ssq_n partials in a fixed order, rstd = rsqrt(sum * inv_h + eps_rs),
+//             and scales the accumulator row by it before anything else happens to it.
 struct EpiArgs {
   bf16* out2;
   long ld2;
   const bf16 *g0, *g1, *cos_t, *sin_t;
   int T, Hq, Hkv, I;
   float eps;
+  float* ssq_out;
+  const float* ssq_in;
+  int ssq_n;
+  float inv_h, eps_rs;
 };
 
 // fp32 C tile in LDS ([BM][128], 16-byte chunks XOR-swizzled by row) -> global, 8 columns per thread.
@@ -184,6 +194,7 @@ struct EpiPre {
   bf16x8 a[(EPI == 1 || EPI == 4 || EPI == 5 || EPI == 6) ? IT : 1];
   bf16x8 b[(EPI == 4 || EPI == 5) ? IT : 1];
   bf16x8 gain;
+  float rs[(EPI == 3 || EPI == 4) ? IT : 1];  // row scale of the folded RMSNorm (1 when ea.ssq_in == nullptr)
 };
 
 template <int EPI, int BM, int NTHR>
@@ -217,6 +228,20 @@ SD_DEV void epi_preload(EpiPre<EPI, BM, NTHR>& pre, const bf16* R, const EpiArgs
     }
     if constexpr (EPI == 4) pre.gain = *(const bf16x8*)((tn < ea.Hq ? ea.g0 : ea.g1) + (threadIdx.x & 15) * 8);
   }
+  if constexpr (EPI == 3 || EPI == 4) {
+    // the 16 threads of a row (one DPP row) fetch one partial each and add them in the fixed butterfly order
+#pragma unroll
+    for (int it = 0; it < BM * 16 / NTHR; ++it) {
+      float rs = 1.f;
+      if (ea.ssq_in) {  // kernel-uniform
+        const int q = it * NTHR + threadIdx.x;
+        const int gm = m0 + (q >> 4), oc = q & 15;
+        const float part = (oc < ea.ssq_n) ? ea.ssq_in[(long)(gm < M ? gm : M - 1) * ea.ssq_n + oc] : 0.f;
+        rs = rsqrtf(row16_sum(part) * ea.inv_h + ea.eps_rs);
+      }
+      pre.rs[it] = rs;
+    }
+  }
 }
 
 template <int EPI, int BM, int NTHR>
@@ -242,7 +267,11 @@ SD_DEV void write_out(const float* cs, bf16* C, const EpiPre<EPI, BM, NTHR>& pre
       const int oc2 = (oc & 7) + 8;
       const f32x4 ulo = *(const f32x4*)(cs + m * 128 + (((2 * oc2) ^ (m & 15)) << 2));
       const f32x4 uhi = *(const f32x4*)(cs + m * 128 + (((2 * oc2 + 1) ^ (m & 15)) << 2));
-      const float u[8] = {ulo[0], ulo[1], ulo[2], ulo[3], uhi[0], uhi[1], uhi[2], uhi[3]};
+      float u[8] = {ulo[0], ulo[1], ulo[2], ulo[3], uhi[0], uhi[1], uhi[2], uhi[3]};
+      if (ea.ssq_in) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { v[e] *= pre.rs[it]; u[e] *= pre.rs[it]; }
+      }
       const int col = tn * 64 + oc * 8;
       if (oc < 8 && gm < M && col < ea.I) {
         bf16x8 gb, ub, ab;
@@ -290,6 +319,10 @@ SD_DEV void write_out(const float* cs, bf16* C, const EpiPre<EPI, BM, NTHR>& pre
       }
     } else if constexpr (EPI == 4) {
       bf16x8 raw;
+      if (ea.ssq_in) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= pre.rs[it];
+      }
 #pragma unroll
       for (int e = 0; e < 8; ++e) raw[e] = (bf16)v[e];
       if (ok) *(bf16x8*)(C + (long)gm * ldc + gn) = raw;
@@ -311,15 +344,22 @@ SD_DEV void write_out(const float* cs, bf16* C, const EpiPre<EPI, BM, NTHR>& pre
         if (ok) *(bf16x8*)(ea.out2 + (long)gm * ea.ld2 + gn) = o;
       }
     } else {
-      if (ok) {
-        if constexpr (EPI == 1) {
+      if constexpr (EPI == 1) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += (float)pre.a[it][e];
+        for (int e = 0; e < 8; ++e) v[e] += (float)pre.a[it][e];
+      }
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
+      if (ok) *(bf16x8*)(C + (long)gm * ldc + gn) = o;
+      if constexpr (EPI == 1) {
+        if (ea.ssq_out) {  // kernel-uniform; every lane of the row takes part in the DPP sum
+          float ss = 0.f;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { const float f = ok ? (float)o[e] : 0.f; ss += f * f; }
+          ss = row16_sum(ss);
+          if (oc == 0 && gm < M) ea.ssq_out[(long)gm * ea.ssq_n + tn] = ss;
         }
-        bf16x8 o;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
-        *(bf16x8*)(C + (long)gm * ldc + gn) = o;
       }
     }
   }
@@ -712,15 +752,49 @@ __global__ __launch_bounds__(768) void gemm_pstag_kernel(const bf16* __restrict_
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     int nxt = DEPTH;
+    // Folded RMSNorm (EPI 3 with ea.ssq_in): the 4 x 64 producer lanes are the 256 rows of the tile being COMPUTED.  In the
+    // tile's first K-step each lane fetches its row's partial sums of squares (4 x 16 B, one 64-byte segment per lane:
+    // 4 KiB contiguous per wave) AHEAD of that step's DMA pieces, so the step's ordinary counted wait covers them (they are
+    // older than the pieces it leaves in flight); then it writes rstd into the LDS table of the tile's parity (the store
+    // patches, idle in this epilogue).  The compute waves read it at the end of the tile, nk K-steps of barriers later.
+    [[maybe_unused]] int ct = 0, ck = 0;  // tile / K-step of the step being computed
     for (int g = 0; g < total; ++g) {
       // phase 2g: K-step g+DEPTH of the stream (steps past the end re-read the first origin and are never used);
       // then everything up to K-step g+1 has landed
       SD_STAMP_DUMP(g);
       SD_STAMP(g, 0);
+      [[maybe_unused]] f32x4 sq[4];
+      bool fold_now = false;
+      if constexpr (EPI == 3) {
+        fold_now = ea.ssq_in != nullptr && ck == 0;  // workgroup-uniform
+        if (fold_now) {
+          int tm, tn;
+          origin(ct, tm, tn);
+          int gm = tm * BM + pw * 64 + lane;
+          gm = gm < M ? gm : M - 1;
+          const int nch = (ea.ssq_n + 3) >> 2;  // f32x4 chunks of a row's partials (ssq_n is a multiple of 4)
+          const float* src = ea.ssq_in + (long)gm * ea.ssq_n;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) sq[c] = *(const f32x4*)(src + 4 * (c < nch ? c : nch - 1));
+        }
+      }
       pf_issue(smem + nxt * STAGE);
       nxt = (nxt == NST - 1) ? 0 : nxt + 1;
       SD_STAMP(g, 1);
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DEPTH - 1) * LOADS) : "memory");
+      if constexpr (EPI == 3) {
+        if (fold_now) {
+          // the same balanced tree as row16_sum over 16 lanes (epi_preload of the one-tile kernels): bit-identical rstd
+          const int nch = (ea.ssq_n + 3) >> 2;
+          float qd[4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) qd[c] = (c < nch) ? (sq[c][0] + sq[c][1]) + (sq[c][2] + sq[c][3]) : 0.f;
+          const float tot = (qd[0] + qd[1]) + (qd[2] + qd[3]);
+          ((float*)(smem + NST * STAGE + (ct & 1) * 1024))[pw * 64 + lane] = rsqrtf(tot * ea.inv_h + ea.eps_rs);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        if (ea.ssq_in && ++ck == nk) { ck = 0; ++ct; }
+      }
       SD_STAMP(g, 2);
       __builtin_amdgcn_s_barrier();
       SD_STAMP(g, 3);
@@ -855,6 +929,9 @@ __global__ __launch_bounds__(768) void gemm_pstag_kernel(const bf16* __restrict_
       for (int i = 0; i < MT; ++i) {
         if constexpr (EPI == 3) {
           const int gm = m0 + wm * WR + i * 16 + (lane & 15);
+          // folded RMSNorm: this row's rstd from the producers' table of this tile (parity of the tile index)
+          const float rsc = ea.ssq_in ? ((const float*)(smem + NST * STAGE + ((ctile - 1) & 1) * 1024))[wm * WR + i * 16 + (lane & 15)]
+                                      : 1.f;
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
             const int gc = tn * 64 + wn * 32 + j * 16 + (lane >> 4) * 4;  // column of act; gate at gc, up at I + gc
@@ -862,7 +939,7 @@ __global__ __launch_bounds__(768) void gemm_pstag_kernel(const bf16* __restrict_
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               // same rounding as the unfused pair: gate|up are rounded to bf16 first (sd_swiglu_fwd reads them back)
-              const bf16 gb = (bf16)acc[i][j][e], ub = (bf16)acc[i][j + 2][e];
+              const bf16 gb = (bf16)(acc[i][j][e] * rsc), ub = (bf16)(acc[i][j + 2][e] * rsc);
               const float gf = (float)gb, uf = (float)ub;
               g4[e] = gb; u4[e] = ub;
               a4[e] = (bf16)(gf / (1.f + __expf(-gf)) * uf);
@@ -1446,7 +1523,8 @@ int launch(const void* A, const void* B, void* C, const void* R, float* slabs, i
       /* many-column forward GEMMs: 256 x 256 tiles when they still fill >= 70 % of the CUs' rounds */               \
       const int t_m = (M + 255) / 256, t_n = (EPI == 3) ? (ea.I + 127) / 128 : (N + 255) / 256, nt2 = t_m * t_n;       \
       const int rounds = persist_grid > 0 ? (nt2 + persist_grid - 1) / persist_grid : 0;                              \
-      if (splits == 1 && !R && p256_ok && persist_grid > 0 && (K % P2_BK) == 0 && (EPI != 3 || (ea.I % 128) == 0) &&   \
+      if (splits == 1 && !R && !ea.ssq_in && p256_ok && persist_grid > 0 && (K % P2_BK) == 0 &&                         \
+          (EPI != 3 || (ea.I % 128) == 0) &&                                                                          \
           (N % 8) == 0 && nt2 >= p256_min_tiles && 10 * nt2 >= 7 * rounds * persist_grid && span < 0x7fffffffL &&      \
           span_b < 0x7fffffffL) {                                                                                     \
         const int grid2 = nt2 > persist_grid ? persist_grid : nt2;                                                    \
@@ -1721,27 +1799,72 @@ extern "C" int sd_gemm_odx_delta(const void* dy, const void* wo, void* d_ao, con
   return dispatch(dy, wo, d_ao, nullptr, nullptr, 1, M, QD, H, H, QD, QD, 0, 0, 1, (hipStream_t)stream, 6, &ea);
 }
 
+// ---- folded RMSNorm (the frozen teacher's inference forward, sd_hip.h SD_SAVE_NONE_FOLDED): the norm's gain lives in the
+// weight rows of the projection behind it, its row statistic travels as per-tile partial sums of squares [M, K / 128].
+static bool ssq_shape_ok(int K) { return K > 0 && (K % 128) == 0 && K / 128 <= 16 && ((K / 128) % 4) == 0; }
+
+// C [M,N] = A [M,K] . B [N,K]^T + R, and ssq_out [M, N/128] = per 128-column tile sums of squares of the stored bf16 C
+extern "C" int sd_gemm_bf16_ssq(const void* A, const void* B, void* C, const void* R, float* ssq_out, int M, int N, int K,
+                                int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, void* stream) {
+  if (int e = check_args(A, B, C, R, M, N, K, lda, ldb, ldc, ldr, 0, 0)) return e;
+  if (!R || !ssq_out || !ssq_shape_ok(N)) return SD_ERR_UNSUPPORTED;
+  if ((uintptr_t)ssq_out & 15) return SD_ERR_ALIGN;
+  EpiArgs ea{};
+  ea.ssq_out = ssq_out;
+  ea.ssq_n = N / 128;
+  return dispatch(A, B, C, R, nullptr, 1, M, N, K, lda, ldb, ldc, ldr, 0, 0, (hipStream_t)stream, 0, &ea);
+}
+
 // gate|up projection with SwiGLU fused into the epilogue (HF:81-83): act [M,I] = silu(x Wg^T) * (x Wu^T);
 // wgu = [gate rows | up rows] ([2I,K], torch layout); gu_out [M,2I] (gate | up, for the backward) may be NULL.
-extern "C" int sd_gemm_swiglu(const void* x, const void* wgu, void* gu_out, void* act_out, int M, int I, int K,
-                              void* stream) {
+// ssq != NULL: x is the UN-normalised row, wgu carries the norm's gain, ssq [M, K/128] its partial sums of squares.
+static int gemm_swiglu_impl(const void* x, const void* wgu, void* gu_out, void* act_out, const float* ssq, float eps, int M,
+                            int I, int K, void* stream) {
   if (M <= 0 || I <= 0 || K <= 0 || (I % 64) || (K % BK)) return SD_ERR_UNSUPPORTED;
-  if (((uintptr_t)x | (uintptr_t)wgu | (uintptr_t)gu_out | (uintptr_t)act_out) & 15) return SD_ERR_ALIGN;
+  if (((uintptr_t)x | (uintptr_t)wgu | (uintptr_t)gu_out | (uintptr_t)act_out | (uintptr_t)ssq) & 15) return SD_ERR_ALIGN;
+  if (ssq && !ssq_shape_ok(K)) return SD_ERR_UNSUPPORTED;
   EpiArgs ea{};
   ea.out2 = (bf16*)act_out;
   ea.ld2 = I;
   ea.I = I;
+  if (ssq) { ea.ssq_in = ssq; ea.ssq_n = K / 128; ea.inv_h = 1.f / (float)K; ea.eps_rs = eps; }
   return dispatch(x, wgu, gu_out, nullptr, nullptr, 1, M, 2 * I, K, K, K, 2 * I, 0, 0, 0, (hipStream_t)stream, 3, &ea);
+}
+extern "C" int sd_gemm_swiglu(const void* x, const void* wgu, void* gu_out, void* act_out, int M, int I, int K,
+                              void* stream) {
+  return gemm_swiglu_impl(x, wgu, gu_out, act_out, nullptr, 0.f, M, I, K, stream);
+}
+extern "C" int sd_gemm_swiglu_rs(const void* x, const void* wgu, void* gu_out, void* act_out, const float* ssq, float eps,
+                                 int M, int I, int K, void* stream) {
+  if (!ssq) return SD_ERR_SHAPE;
+  return gemm_swiglu_impl(x, wgu, gu_out, act_out, ssq, eps, M, I, K, stream);
 }
 
 // q|k|v projection with the per-head q/k RMSNorm and rotate-half RoPE fused into the epilogue (HF:252-257, 121-170):
 // qkv_out [M,(Hq+2Hkv)*128] raw projections (V for attention, q/k for the backward), qk_out [M,(Hq+Hkv)*128] rotated.
+static int gemm_qkv_rope_impl(const void* x, const void* wqkv, void* qkv_out, void* qk_out, const void* q_gain,
+                              const void* k_gain, const void* cos_tab, const void* sin_tab, const float* ssq, int M, int T,
+                              int Hq, int Hkv, int K, float eps, void* stream);
 extern "C" int sd_gemm_qkv_rope(const void* x, const void* wqkv, void* qkv_out, void* qk_out, const void* q_gain,
                                 const void* k_gain, const void* cos_tab, const void* sin_tab, int M, int T, int Hq,
                                 int Hkv, int K, float eps, void* stream) {
+  return gemm_qkv_rope_impl(x, wqkv, qkv_out, qk_out, q_gain, k_gain, cos_tab, sin_tab, nullptr, M, T, Hq, Hkv, K, eps, stream);
+}
+// ssq [M, K/128]: x is the UN-normalised row and wqkv carries the input norm's gain (see sd_gemm_bf16_ssq)
+extern "C" int sd_gemm_qkv_rope_rs(const void* x, const void* wqkv, void* qkv_out, void* qk_out, const void* q_gain,
+                                   const void* k_gain, const void* cos_tab, const void* sin_tab, const float* ssq, int M,
+                                   int T, int Hq, int Hkv, int K, float eps, void* stream) {
+  if (!ssq) return SD_ERR_SHAPE;
+  return gemm_qkv_rope_impl(x, wqkv, qkv_out, qk_out, q_gain, k_gain, cos_tab, sin_tab, ssq, M, T, Hq, Hkv, K, eps, stream);
+}
+static int gemm_qkv_rope_impl(const void* x, const void* wqkv, void* qkv_out, void* qk_out, const void* q_gain,
+                              const void* k_gain, const void* cos_tab, const void* sin_tab, const float* ssq, int M, int T,
+                              int Hq, int Hkv, int K, float eps, void* stream) {
   if (M <= 0 || T <= 0 || (M % T) || K <= 0 || (K % BK) || !qkv_out || !qk_out) return SD_ERR_UNSUPPORTED;
-  if (((uintptr_t)x | (uintptr_t)wqkv | (uintptr_t)qkv_out | (uintptr_t)qk_out) & 15) return SD_ERR_ALIGN;
+  if (((uintptr_t)x | (uintptr_t)wqkv | (uintptr_t)qkv_out | (uintptr_t)qk_out | (uintptr_t)ssq) & 15) return SD_ERR_ALIGN;
+  if (ssq && !ssq_shape_ok(K)) return SD_ERR_UNSUPPORTED;
   EpiArgs ea{};
+  if (ssq) { ea.ssq_in = ssq; ea.ssq_n = K / 128; ea.inv_h = 1.f / (float)K; ea.eps_rs = eps; }
   ea.out2 = (bf16*)qk_out;
   ea.ld2 = (long)(Hq + Hkv) * 128;
   ea.g0 = (const bf16*)q_gain;

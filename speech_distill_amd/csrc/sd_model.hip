@@ -26,12 +26,13 @@ struct Sizes {
   }
   int64_t per_layer() const { return 4 * x + 2 * rstd + qkv + qk + ao + lse + gu + act; }
   int64_t tail() const { return 3 * x + rstd; }  // x_last, rstd_f, xn_f, xn_rows (head rows gathered)
+  int64_t ssq() const { return al((int64_t)M * 16 * 4); }  // one set of per-tile sums of squares (folded norms)
   // activation storage by mode (sd_hip.h SD_SAVE_*): every layer's buffers | L layer inputs + two layer work sets
   // (recompute; two, because the grouped dW of layer l still reads its set while layer l-1 is recomputed) | one set
   // + a ping-pong x (inference)
   int64_t body(int save) const {
     return save == SD_SAVE_ALL ? (int64_t)L * per_layer() : save == SD_SAVE_LAYER_INPUTS ? (int64_t)L * x + 2 * per_layer()
-                                                                                          : per_layer() + x;
+                                                                                          : per_layer() + x;  // both inference modes
   }
 };
 
@@ -138,6 +139,30 @@ int layer_forward(const sd_qwen3_dims* d, const Sizes& s, const LayerActs& a, co
   return 0;
 }
 
+// The same layer for the frozen teacher with the two RMSNorm gains folded into w.wqkv / w.wgu (SD_SAVE_NONE_FOLDED,
+// HF:59-64 + 252-254 / 81-83): no norm launch, no normalised copy of the row.  ssq_in: partial sums of squares of a.x_in
+// (from the embedding or the previous layer's down projection); ssq_mid: scratch for those of a.x_mid; ssq_next
+// (nullable): where the down projection leaves those of x_out for the next layer.  w.ln1 / w.ln2 are not read.
+int layer_forward_folded(const sd_qwen3_dims* d, const Sizes& s, const LayerActs& a, const sd_qwen3_layer& w, char* x_out,
+                         const int32_t* kv_len, const void* cos_tab, const void* sin_tab, int B, int T, const float* ssq_in,
+                         float* ssq_mid, float* ssq_next, void* stream) {
+  const float scale = 0.08838834764831845f;
+  RUN(sd_gemm_qkv_rope_rs(a.x_in, w.wqkv, a.qkv, a.qk, w.q_gain, w.k_gain, cos_tab, sin_tab, ssq_in, s.M, T, s.Hq, s.Hkv,
+                          s.h, d->eps, stream));
+  RUN(sd_attn_fwd(a.qk, a.qk + (int64_t)s.QD * 2, a.qkv + (int64_t)(s.QD + s.KD) * 2, a.ao, (float*)a.lse, kv_len,
+                  s.QK, s.QK, s.QKV, s.QD, B, T, s.Hq, s.Hkv, 128, scale, stream));
+  RUN(sd_gemm_bf16_ssq(a.ao, w.wo, a.x_mid, a.x_in, ssq_mid, s.M, s.h, s.QD, s.QD, s.QD, s.h, s.h, stream));
+  RUN(sd_gemm_swiglu_rs(a.x_mid, w.wgu, nullptr, a.act, ssq_mid, d->eps, s.M, s.I, s.h, stream));
+  if (ssq_next) RUN(sd_gemm_bf16_ssq(a.act, w.wdown, x_out, a.x_mid, ssq_next, s.M, s.h, s.I, s.I, s.I, s.h, s.h, stream));
+  else RUN(sd_gemm_bf16(a.act, w.wdown, x_out, a.x_mid, s.M, s.h, s.I, s.I, s.I, s.h, s.h, 0, 0, stream));
+  return 0;
+}
+
+bool fold_supported(const sd_qwen3_dims* d) {
+  const int h = d->hidden;
+  return d->head_dim == 128 && (h % 512) == 0 && h / 128 <= 16 && (d->inter % 64) == 0;
+}
+
 }  // namespace
 
 namespace {
@@ -174,9 +199,12 @@ void sd_return_events(SdEventSet* s) {
 
 extern "C" int sd_abi_version(void) { return 1; }
 
+extern "C" int sd_qwen3_fold_supported(const sd_qwen3_dims* d) { return d && fold_supported(d) ? 1 : 0; }
+
 extern "C" int64_t sd_qwen3_acts_bytes(const sd_qwen3_dims* d, int B, int T, int save) {
   Sizes s(d, B, T);
-  if (save < SD_SAVE_NONE || save > SD_SAVE_LAYER_INPUTS) return SD_ERR_SHAPE;
+  if (save < SD_SAVE_NONE || save > SD_SAVE_NONE_FOLDED) return SD_ERR_SHAPE;
+  if (save == SD_SAVE_NONE_FOLDED) return fold_supported(d) ? s.body(SD_SAVE_NONE) + s.tail() + 2 * s.ssq() : SD_ERR_UNSUPPORTED;
   return s.body(save) + s.tail();
 }
 
@@ -201,7 +229,13 @@ extern "C" int sd_qwen3_forward_rows(const sd_qwen3_dims* d, const sd_qwen3_para
   if (B <= 0 || T <= 0) return SD_ERR_SHAPE;
   if (head_rows && (n_head_rows <= 0 || n_head_rows > B * T)) return SD_ERR_SHAPE;
   Sizes s(d, B, T);
-  if (save < SD_SAVE_NONE || save > SD_SAVE_LAYER_INPUTS) return SD_ERR_SHAPE;
+  if (save < SD_SAVE_NONE || save > SD_SAVE_NONE_FOLDED) return SD_ERR_SHAPE;
+  const bool folded = save == SD_SAVE_NONE_FOLDED;
+  if (folded) {
+    if (!fold_supported(d)) return SD_ERR_UNSUPPORTED;
+    if (acts_bytes < sd_qwen3_acts_bytes(d, B, T, save)) return SD_ERR_WORKSPACE;
+    save = SD_SAVE_NONE;  // same buffers as the plain inference forward, plus the two ssq sets behind the tail
+  }
   if (acts_bytes < sd_qwen3_acts_bytes(d, B, T, save)) return SD_ERR_WORKSPACE;
   char* base = (char*)acts;
   char* tail = base + s.body(save);
@@ -210,16 +244,23 @@ extern "C" int sd_qwen3_forward_rows(const sd_qwen3_dims* d, const sd_qwen3_para
   char* xn_f = rstd_f + s.rstd;
   char* xn_rows = xn_f + s.x;
   char* pong = base + s.per_layer();  // inference only
+  float* ssq_a = (float*)(tail + s.tail());  // folded inference only
+  float* ssq_b = (float*)(tail + s.tail() + s.ssq());
 
   char* x_cur = save ? layer_acts(s, base, 0, save).x_in : base;
-  RUN(sd_embedding_fwd(ids, p->embed, x_cur, s.M, s.h, s.V, stream));
+  if (folded) RUN(sd_embedding_fwd_ssq(ids, p->embed, x_cur, ssq_a, s.M, s.h, s.V, stream));
+  else RUN(sd_embedding_fwd(ids, p->embed, x_cur, s.M, s.h, s.V, stream));
   for (int l = 0; l < s.L; ++l) {
     LayerActs a = save ? layer_acts(s, base, l, save) : carve(s, base);
     a.x_in = x_cur;
     char* x_out;
     if (save) x_out = (l + 1 < s.L) ? layer_acts(s, base, l + 1, save).x_in : x_last;
     else x_out = (l + 1 < s.L) ? ((x_cur == pong) ? base : pong) : x_last;
-    RUN(layer_forward(d, s, a, p->layers_host[l], x_out, save != SD_SAVE_NONE, kv_len, cos_tab, sin_tab, B, T, stream));
+    if (folded)
+      RUN(layer_forward_folded(d, s, a, p->layers_host[l], x_out, kv_len, cos_tab, sin_tab, B, T, ssq_a, ssq_b,
+                               l + 1 < s.L ? ssq_a : nullptr, stream));
+    else
+      RUN(layer_forward(d, s, a, p->layers_host[l], x_out, save != SD_SAVE_NONE, kv_len, cos_tab, sin_tab, B, T, stream));
     x_cur = x_out;
   }
   RUN(sd_rmsnorm_fwd(x_last, p->final_norm, xn_f, (float*)rstd_f, s.M, s.h, d->eps, stream));

@@ -550,3 +550,44 @@ def gemm_qkv_rope(x, wqkv, q_gain, k_gain, cos, sin, T, Hq, Hkv, eps=1e-6):
                                       k_gain.data_ptr(), cos.data_ptr(), sin.data_ptr(), M, T, Hq, Hkv, K, eps, _stream()),
           "sd_gemm_qkv_rope")
     return qkv, qk
+
+
+# ---- RMSNorm folded into the projection behind it (include/sd_hip.h "RMSNorm folded ..."; the frozen teacher)
+def embedding_fwd_ssq(ids, E):
+    ids = _need(ids, torch.int64, "ids").reshape(-1)
+    V, H = E.shape
+    x = torch.empty(ids.numel(), H, dtype=torch.bfloat16, device=E.device)
+    ssq = torch.empty(ids.numel(), H // 128, dtype=torch.float32, device=E.device)
+    check(load_lib().sd_embedding_fwd_ssq(ids.data_ptr(), _p(E), x.data_ptr(), ssq.data_ptr(), ids.numel(), H, V, _stream()),
+          "sd_embedding_fwd_ssq")
+    return x, ssq
+
+
+def gemm_resid_ssq(a, w, residual):
+    """C = a . w^T + residual and the per-128-column-tile sums of squares of C: ([M,N] bf16, [M,N/128] fp32)."""
+    M, K = a.shape
+    N = w.shape[0]
+    c = torch.empty(M, N, dtype=torch.bfloat16, device=a.device)
+    ssq = torch.empty(M, N // 128, dtype=torch.float32, device=a.device)
+    check(load_lib().sd_gemm_bf16_ssq(_p(a), _p(w), c.data_ptr(), _p(residual), ssq.data_ptr(), M, N, K, a.stride(0),
+                                      w.stride(0), N, residual.stride(0), _stream()), "sd_gemm_bf16_ssq")
+    return c, ssq
+
+
+def gemm_swiglu_rs(x, wgu_folded, ssq, eps=1e-6, save_gu=False):
+    M, K = x.shape
+    I = wgu_folded.shape[0] // 2
+    act = torch.empty(M, I, dtype=torch.bfloat16, device=x.device)
+    gu = torch.empty(M, 2 * I, dtype=torch.bfloat16, device=x.device) if save_gu else None
+    check(load_lib().sd_gemm_swiglu_rs(_p(x), _p(wgu_folded), _p(gu), act.data_ptr(), _p(ssq), eps, M, I, K, _stream()),
+          "sd_gemm_swiglu_rs")
+    return act, gu
+
+
+def gemm_qkv_rope_rs(x, wqkv_folded, q_gain, k_gain, cos, sin, ssq, T, Hq, Hkv, eps=1e-6):
+    M, K = x.shape
+    qkv = torch.empty(M, (Hq + 2 * Hkv) * 128, dtype=torch.bfloat16, device=x.device)
+    qk = torch.empty(M, (Hq + Hkv) * 128, dtype=torch.bfloat16, device=x.device)
+    check(load_lib().sd_gemm_qkv_rope_rs(_p(x), _p(wqkv_folded), qkv.data_ptr(), qk.data_ptr(), _p(q_gain), _p(k_gain),
+                                         _p(cos), _p(sin), _p(ssq), M, T, Hq, Hkv, K, eps, _stream()), "sd_gemm_qkv_rope_rs")
+    return qkv, qk

@@ -99,7 +99,7 @@ class CausalLMOutput(dict):
             raise AttributeError(k) from e
 
 
-SAVE_NONE, SAVE_ALL, SAVE_LAYER_INPUTS = 0, 1, 2  # include/sd_hip.h SD_SAVE_*
+SAVE_NONE, SAVE_ALL, SAVE_LAYER_INPUTS, SAVE_NONE_FOLDED = 0, 1, 2, 3  # include/sd_hip.h SD_SAVE_*
 BWD_ACCUMULATE, BWD_RECOMPUTE = 1, 2              # SD_BWD_*
 
 
@@ -203,6 +203,11 @@ class HipQwen3ForCausalLM(nn.Module):
         # (data.py:280-327).  ``forward`` checks the mask for that (one host read); a caller that has already checked
         # (DistillationTrainer folds it into the row-count read it needs anyway) passes ``padding_checked=True``.
         self.validate_padding = True
+        # A FROZEN model (the teacher: train.py:165-169) runs its inference forward with every decoder layer's RMSNorm
+        # gains folded into the q|k|v / gate|up weights (SD_SAVE_NONE_FOLDED: 1 instead of 2L+1 norm launches per pass);
+        # the folded copies are rebuilt whenever the flat parameter buffer has been written to (version counter).
+        self.fold_norm_gains = True
+        self._folded = None  # (flat._version, folded weight buffer, Params, Layers)
         if init_std:
             self.init_weights(seed, init_std)
 
@@ -432,18 +437,54 @@ class HipQwen3ForCausalLM(nn.Module):
             self._rope[key] = rope_tables(T, device, self.dims.rope_theta)
         return self._rope[key]
 
+    @torch.no_grad()
+    def _folded_params(self):
+        """C parameter struct whose wqkv / wgu point at W diag(g) (g = the RMSNorm gain in front of the projection,
+        HF:59-64, 252-254, 81-83), or None when this model must not or cannot fold."""
+        if not self.fold_norm_gains or any(p.requires_grad for p in self._params.values()):
+            return None
+        if not load_lib().sd_qwen3_fold_supported(C.byref(self._cdims)):
+            return None
+        ver = self.flat._version
+        if self._folded is not None and self._folded[0] == ver and self._folded[1].device == self.flat.device:
+            return self._folded[2]
+        d = self.dims
+        h, I = d.hidden_size, d.intermediate_size
+        nq, ng = (d.q_dim + 2 * d.kv_dim) * h, 2 * I * h
+        buf = torch.empty(d.num_hidden_layers * (nq + ng), dtype=torch.bfloat16, device=self.flat.device)
+        params, layers = self._c_struct(self.flat)
+        for l in range(d.num_hidden_layers):
+            p = f"model.layers.{l}."
+            o, _, _ = self._slices[p + "self_attn.q_proj.weight"]
+            wqkv = self.flat[o:o + nq].view(-1, h)       # q | k | v rows are contiguous in the flat layout
+            o, _, _ = self._slices[p + "mlp.gate_proj.weight"]
+            wgu = self.flat[o:o + ng].view(-1, h)        # gate | up likewise
+            base = l * (nq + ng)
+            fq, fg = buf[base:base + nq].view(-1, h), buf[base + nq:base + nq + ng].view(-1, h)
+            fq.copy_(wqkv.float() * self._params[p + "input_layernorm.weight"].float()[None, :])
+            fg.copy_(wgu.float() * self._params[p + "post_attention_layernorm.weight"].float()[None, :])
+            layers[l].wqkv = buf.data_ptr() + base * 2
+            layers[l].wgu = buf.data_ptr() + (base + nq) * 2
+        self._folded = (ver, buf, params, layers)
+        return params
+
     def _run_forward(self, input_ids, kv_len, save, rows=None):
         lib = load_lib()
         B, T = input_ids.shape
         dev = input_ids.device
         cos, sin = self._tables(T, dev)
+        cparams = self._cparams
+        if save == SAVE_NONE:
+            folded = self._folded_params()
+            if folded is not None:
+                cparams, save = folded, SAVE_NONE_FOLDED
         nbytes = lib.sd_qwen3_acts_bytes(C.byref(self._cdims), B, T, int(save))
         acts = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         if rows is None:
             logits = torch.empty(B, T, self.dims.vocab_size, dtype=torch.bfloat16, device=dev)
         else:
             logits = torch.empty(rows.numel(), self.dims.vocab_size, dtype=torch.bfloat16, device=dev)
-        check(lib.sd_qwen3_forward_rows(C.byref(self._cdims), C.byref(self._cparams), input_ids.data_ptr(), _p(kv_len),
+        check(lib.sd_qwen3_forward_rows(C.byref(self._cdims), C.byref(cparams), input_ids.data_ptr(), _p(kv_len),
                                         cos.data_ptr(), sin.data_ptr(), acts.data_ptr(), nbytes, logits.data_ptr(),
                                         _p(rows), 0 if rows is None else rows.numel(), B, T, int(save), _stream()),
               "sd_qwen3_forward_rows")

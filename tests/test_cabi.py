@@ -43,7 +43,9 @@ def test_workspace_queries_run_without_gpu():
     # SD_SAVE_LAYER_INPUTS (gradient checkpointing): 28 layer inputs + two layer work sets instead of 28 sets
     ckpt = lib.sd_qwen3_acts_bytes(ctypes.byref(d), 4, 512, 2)
     assert infer < ckpt < train / 8
-    assert lib.sd_qwen3_acts_bytes(ctypes.byref(d), 4, 512, 3) < 0  # unknown mode: SD_ERR_SHAPE, not a size
+    assert lib.sd_qwen3_acts_bytes(ctypes.byref(d), 4, 512, 4) < 0  # unknown mode: SD_ERR_SHAPE, not a size
+    folded = lib.sd_qwen3_acts_bytes(ctypes.byref(d), 4, 512, 3)  # SD_SAVE_NONE_FOLDED: the inference set + two ssq sets
+    assert infer < folded <= infer + 2 * (4 * 512 * 64 + 256)
     assert lib.sd_kdloss_stats_bytes(4, 512) == 4 * 512 * 32
     assert lib.sd_gemm_splitk_plan(2048, 1024, 159488) > 1 and lib.sd_gemm_splitk_plan(2048, 6144, 1024) == 1
 

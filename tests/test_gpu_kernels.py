@@ -149,6 +149,99 @@ def test_gemm_fused_epilogues_equal_the_separate_kernels(ops, bm, nst):
     assert torch.equal(act, act_ref) and torch.equal(act2, act_ref), float((act.float() - act_ref.float()).abs().max())
 
 
+@pytest.mark.parametrize("H", [1024, 2048])
+def test_folded_rmsnorm_pieces(ops, O, H):
+    """RMSNorm folded into the projection behind it (include/sd_hip.h; the frozen teacher's inference forward): the
+    producers of the row statistic (embedding lookup, residual GEMM epilogue) leave per-128-column-tile sums of squares,
+    the consumers (q|k|v + q/k-norm + RoPE, gate|up + SwiGLU) turn them into rstd and scale the accumulator row.
+    * producers: the bf16 outputs are bit-identical to the plain launchers; the partials equal the fp64 sums of squares
+      of those bf16 values to fp32 rounding, and are bit-identical across kernel variants;
+    * consumers: every kernel variant -- the one-tile kernels (rstd via a DPP sum in the epilogue preload) AND the
+      persistent 256x128 kernel (rstd via the producer waves' LDS table) -- gives the same bits; against an fp64
+      evaluation of  rstd * (x W'^T)  followed by the unfused epilogue arithmetic: one bf16 rounding."""
+    Q = O.Q
+    g = torch.Generator().manual_seed(H)
+    eps = 1e-6
+    V, M, T, Hq, Hkv, I, Kd = 3000, 2 * 150, 150, 4, 2, 64 * 3, 384
+    nt = H // 128
+    # ---- producers
+    E = to_dev(bf(torch.randn(V, H, generator=g)))
+    ids = to_dev(torch.randint(0, V, (M,), generator=g))
+    x0, ssq0 = ops.embedding_fwd_ssq(ids, E)
+    assert torch.equal(x0, ops.embedding_fwd(ids, E))
+    want0 = x0.double().view(M, nt, 128).pow(2).sum(-1)
+    np.testing.assert_allclose(ssq0.double().cpu().numpy(), want0.cpu().numpy(), rtol=1e-5)
+    a = to_dev(bf(torch.randn(M, Kd, generator=g)))
+    w = to_dev(bf(torch.randn(H, Kd, generator=g) * 0.05))
+    c_ref = ops.gemm(a, w, residual=x0)
+    outs = []
+    for bm, nst in ((0, 0), (64, 4), (128, 3), (256, 9)):
+        _lib.gemm_force_variant(bm, nst)
+        try:
+            outs.append(ops.gemm_resid_ssq(a, w, x0))
+        finally:
+            _lib.gemm_force_variant(0, 0)
+    x1, ssq1 = outs[0]
+    for c, sq in outs:
+        assert torch.equal(c, c_ref) and torch.equal(sq, ssq1)
+    np.testing.assert_allclose(ssq1.double().cpu().numpy(), x1.double().view(M, nt, 128).pow(2).sum(-1).cpu().numpy(), rtol=1e-5)
+    # ---- consumers: weights with the norm's gain folded in
+    gain = bf(1 + 0.3 * torch.randn(H, generator=g))
+    wqkv = bf(torch.randn((Hq + 2 * Hkv) * 128, H, generator=g) * 0.05)
+    wgu = bf(torch.randn(2 * I, H, generator=g) * 0.05)
+    wqkv_f, wgu_f = bf(wqkv.float() * gain.float()[None]), bf(wgu.float() * gain.float()[None])
+    qg, kg = bf(1 + 0.2 * torch.randn(128, generator=g)), bf(1 + 0.2 * torch.randn(128, generator=g))
+    cos, sin = ops.rope_tables(T, dev())
+    res_q, res_s = [], []
+    for bm, nst in ((0, 0), (64, 4), (128, 3), (256, 9)):
+        _lib.gemm_force_variant(bm, nst)
+        try:
+            res_q.append(ops.gemm_qkv_rope_rs(x1, to_dev(wqkv_f), to_dev(qg), to_dev(kg), cos, sin, ssq1, T, Hq, Hkv, eps))
+            res_s.append(ops.gemm_swiglu_rs(x1, to_dev(wgu_f), ssq1, eps, save_gu=True))
+        finally:
+            _lib.gemm_force_variant(0, 0)
+    for (qkv, qk), (act, gu) in zip(res_q, res_s):
+        assert torch.equal(qkv, res_q[0][0]) and torch.equal(qk, res_q[0][1])
+        assert torch.equal(act, res_s[0][0]) and torch.equal(gu, res_s[0][1])
+    # fp64 statement: rstd from the bf16 row, scale the exact product, then the unfused epilogues' roundings
+    xd = x1.double().cpu()
+    rstd = (xd.pow(2).mean(-1, keepdim=True) + eps).rsqrt()
+    raw = bf((rstd * (xd @ wqkv_f.double().T)).float())
+    check_close(f"fold_qkv_raw_H{H}", res_q[0][0], raw, 8e-3, 2e-3)
+    qh = raw.float().view(2, T, Hq + 2 * Hkv, 128)
+    qn = Q.rms_norm(qh[:, :, :Hq].bfloat16(), qg, eps).transpose(1, 2)
+    kn = Q.rms_norm(qh[:, :, Hq:Hq + Hkv].bfloat16(), kg, eps).transpose(1, 2)
+    cs, sn = cos.cpu().float(), sin.cpu().float()
+    qr = Q.apply_rope(qn.float(), cs, sn).transpose(1, 2).reshape(M, Hq * 128)
+    kr = Q.apply_rope(kn.float(), cs, sn).transpose(1, 2).reshape(M, Hkv * 128)
+    check_close(f"fold_qk_rot_H{H}", res_q[0][1], torch.cat([qr, kr], -1), 2.5e-2, 5e-3)
+    gud = bf((rstd * (xd @ wgu_f.double().T)).float())
+    check_close(f"fold_gu_H{H}", res_s[0][1], gud, 8e-3, 2e-3)
+    gf, uf = res_s[0][1][:, :I].float(), res_s[0][1][:, I:].float()
+    assert torch.equal(res_s[0][0], bf(torch.nn.functional.silu(gf) * uf)) or \
+        float((res_s[0][0].float() - torch.nn.functional.silu(gf) * uf).abs().max()) <= 4e-3 * float(uf.abs().max())
+    # ---- the persistent 256x128 kernel (more tiles than CUs): its producer-wave rstd table against the one-tile kernels
+    Mp, Ip = 2100, 64 * 40
+    xp = to_dev(bf(torch.randn(Mp, H, generator=g)))
+    rp = to_dev(bf(torch.randn(Mp, H, generator=g)))
+    xp2, ssqp = ops.gemm_resid_ssq(to_dev(bf(torch.randn(Mp, 128, generator=g))), to_dev(bf(torch.randn(H, 128, generator=g) * 0.1)), rp)
+    wp = to_dev(bf(torch.randn(2 * Ip, H, generator=g) * 0.05))
+    _lib.debug_set("gemm.no_p256", 1)
+    try:
+        ops.prof_begin()
+        act_p, gu_p = ops.gemm_swiglu_rs(xp2, wp, ssqp, eps, save_gu=True)
+        act_p2, _ = ops.gemm_swiglu_rs(xp2, wp, ssqp, eps)
+        ops.prof_end()
+        assert any(k.startswith("gemm_pstag_kernel<4, false, false, 3>") for k in ops.prof_symbols()), ops.prof_symbols()
+        _lib.gemm_force_variant(128, 3)
+        act_1, gu_1 = ops.gemm_swiglu_rs(xp2, wp, ssqp, eps, save_gu=True)
+    finally:
+        _lib.gemm_force_variant(0, 0)
+        _lib.debug_set("gemm.no_p256", 0)
+    assert torch.equal(gu_p, gu_1) and torch.equal(act_p, act_1) and torch.equal(act_p2, act_1)
+    del xp
+
+
 @pytest.mark.parametrize("K", [64, 128, 192, 1088])
 @pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, True)])
 def test_gemm_persistent_kernel(ops, ta, tb, K):

@@ -66,13 +66,64 @@ def test_qwen3_forward_backward_vs_hf_fixture(sda):
 
 
 def test_qwen3_inference_path_equals_training_path(sda):
-    """The teacher (no-grad, ping-pong buffers) and student (saved activations) forwards are the same kernels."""
+    """The no-grad forward (ping-pong buffers) and the training forward (saved activations) are the same kernels: equal
+    bits.  (A model with trainable parameters never folds its norm gains: they change every optimizer step.)"""
     model = sda.HipQwen3ForCausalLM(sda.Qwen3Dims(1000, 256, 512, 3, 4, 2), device=dev(), seed=3)
     ids = torch.randint(0, 1000, (2, 70), device=dev())
     a = model(input_ids=ids).logits
     with torch.no_grad():
         b = model(input_ids=ids).logits
-    assert torch.equal(a, b)
+    assert torch.equal(a, b) and model._folded is None
+
+
+def test_folded_teacher_forward_matches_unfolded(sda):
+    """The FROZEN teacher's inference forward folds every decoder layer's RMSNorm gains into the q|k|v / gate|up weights
+    (SD_SAVE_NONE_FOLDED; train.py:60-69, 165-169): one rmsnorm launch per pass instead of 2L+1.  Arithmetic order
+    changes (the gain meets the weight, the normalised row is never rounded to bf16), so this is a TOLERANCE test:
+    against the fp32 oracle (gains jittered away from 1 so a lost / doubled gain shows) the folded logits must be no
+    further off than 1.5 x the unfolded ones, and within the bf16 tolerance of the G5 test; refolds when the weights are
+    reloaded; right-padded batch; logit_rows."""
+    from oracle import qwen3 as Q
+    from speech_distill_amd import ops
+    shp = Q.Qwen3Shape(1200, 512, 1024, 3, 4, 2)
+    w = {k: v.bfloat16().float() for k, v in Q.init_weights(shp, seed=9, norm_jitter=0.25).items()}
+    model = _build(sda, (1200, 512, 1024, 3, 4, 2), w)
+    model.eval().requires_grad_(False)
+    g = torch.Generator().manual_seed(3)
+    ids = torch.randint(0, 1200, (3, 90), generator=g)
+    am = torch.ones(3, 90, dtype=torch.long)
+    am[1, 61:] = 0
+    ref = Q.forward(w, shp, ids, am)[am.bool()]
+    ops.prof_begin()
+    with torch.no_grad():
+        folded = model(input_ids=to_dev(ids), attention_mask=to_dev(am)).logits
+    ops.prof_end()
+    syms = ops.prof_symbols()
+    assert model._folded is not None
+    assert sum(v[2] for k, v in syms.items() if k.startswith("rmsnorm_fwd_kernel")) == 1, syms  # the final norm only
+    model.fold_norm_gains = False
+    ops.prof_begin()
+    with torch.no_grad():
+        plain = model(input_ids=to_dev(ids), attention_mask=to_dev(am)).logits
+    ops.prof_end()
+    assert sum(v[2] for k, v in ops.prof_symbols().items() if k.startswith("rmsnorm_fwd_kernel")) == 2 * 3 + 1
+    model.fold_norm_gains = True
+    m = am.bool()
+    ef = check_close("folded_teacher_logits", folded.float().cpu()[m], ref, 6e-2, 1.5e-2)
+    ep = check_close("unfolded_teacher_logits", plain.float().cpu()[m], ref, 6e-2, 1.5e-2)
+    record("folded_vs_unfolded", rms_folded=ef[1], rms_unfolded=ep[1])
+    assert ef[1] <= 1.5 * ep[1], (ef, ep)
+    # logit_rows on the folded path = the same rows of the full folded output
+    rows = to_dev(torch.tensor([0, 5, 89, 90 + 60, 2 * 90 + 7]))
+    with torch.no_grad():
+        some = model(input_ids=to_dev(ids), attention_mask=to_dev(am), logit_rows=rows).logits
+    check_close("folded_rows", some, folded.view(-1, 1200)[rows], 1e-2, 2e-3)  # lm_head tile variant may differ
+    # new weights -> the folded copies are rebuilt (version counter of the flat buffer)
+    w2 = {k: v.bfloat16().float() for k, v in Q.init_weights(shp, seed=10, norm_jitter=0.25).items()}
+    model.load_hf_state_dict(w2)
+    with torch.no_grad():
+        f2 = model(input_ids=to_dev(ids), attention_mask=to_dev(am)).logits
+    check_close("folded_teacher_logits_reloaded", f2.float().cpu()[m], Q.forward(w2, shp, ids, am)[m], 6e-2, 1.5e-2)
 
 
 def test_gradient_accumulation_adds(sda):
