@@ -98,6 +98,63 @@ def cpu_baseline(sample_T, threads, n_seq=2):
     return res, sw, tw, batch, out
 
 
+def measure_traffic(symbol, timeout_s=170):
+    """`roofline.traffic`, MEASURED in this very run: two child runs of this script under
+    `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, nothing else traced; 2 steps on one stream), the
+    counter rows of the dominant kernel symbol averaged per launch.  Units / corrections per MI355X_MICROARCH.md section
+    HBM: KB; FETCH_SIZE x 2 on gfx950 -- re-calibrated for the GEMMs' own load path (`buffer_load ... lds`, private and
+    panel-shared streams: factor 1.9999 / 1.9986) in profiles/r04_fetch_calibration.json.  Fabric-side bytes: Infinity-
+    Cache hits are counted.  On any failure (rocprofv3 absent, timeout) the value of the committed profile is reported
+    and SAID to be that."""
+    import shutil
+    import subprocess
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    out = {}
+    try:
+        from pmc_summary import per_kernel, symbol as sym_of
+        if shutil.which("rocprofv3") is None:
+            raise RuntimeError("rocprofv3 not on PATH")
+        got = {}
+        for ctr, mul in (("FETCH_SIZE", 2048.0), ("WRITE_SIZE", 1024.0)):
+            d = tempfile.mkdtemp(prefix="sd_pmc_", dir="/tmp")
+            env = dict(os.environ, TMPDIR="/tmp")
+            cmd = ["rocprofv3", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "run", "--", sys.executable,
+                   os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-prof",
+                   "--no-overlap", "--no-traffic"]
+            subprocess.run(cmd, cwd="/tmp", env=env, timeout=timeout_s, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                           check=True)
+            n = v = 0
+            for raw, (cnt, val) in per_kernel(d, ctr).items():
+                if sym_of(raw) == symbol:
+                    n += cnt
+                    v += val
+            shutil.rmtree(d, ignore_errors=True)
+            if not n:
+                raise RuntimeError(f"{symbol} not in the {ctr} pass")
+            got[ctr] = (v * mul / n, n)
+        out["traffic"] = got["FETCH_SIZE"][0] + got["WRITE_SIZE"][0]
+        out["traffic_parts"] = {"fetch_bytes_per_launch": got["FETCH_SIZE"][0], "write_bytes_per_launch": got["WRITE_SIZE"][0],
+                                "launches_seen": got["FETCH_SIZE"][1]}
+        out["traffic_source"] = ("measured in this run: child `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` passes of "
+                                 "`bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-prof --no-overlap`; KB units, FETCH_SIZE x2 "
+                                 "(gfx950; calibrated for buffer_load ... lds in profiles/r04_fetch_calibration.json); "
+                                 "fabric-side bytes, Infinity-Cache hits counted")
+    except Exception as e:  # noqa: BLE001
+        out["traffic"] = None
+        out["traffic_source"] = f"live measurement failed ({e!r})"
+        for prof in ("r04_pmc_traffic.json", "r03_pmc_traffic.json"):
+            pth = os.path.join(ROOT, "profiles", prof)
+            if os.path.exists(pth):
+                t = json.load(open(pth))
+                ent = t.get("kernels", {}).get(symbol)
+                if ent is not None:
+                    out["traffic"] = ent["hbm_bytes_per_launch"]
+                    out["traffic_source"] += f"; value REPLAYED from the committed profiles/{prof}"
+                    break
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -130,6 +187,8 @@ def main():
                     help="MEASUREMENT ONLY (not the reported configuration): select the loss rows once instead of every "
                          "step -- an upper bound on what the per-step host read of the row count costs")
     ap.add_argument("--no-overlap", action="store_true", help="single stream everywhere (clean per-kernel profiles)")
+    ap.add_argument("--no-traffic", action="store_true",
+                    help="skip the live `roofline.traffic` measurement (two child runs of this script under rocprofv3 --pmc)")
     ap.add_argument("--no-fold", action="store_true",
                     help="A/B: the frozen teacher runs its RMSNorm launches instead of folding the gains into the weights")
     ap.add_argument("--experiment-cu-hog", type=int, default=0, metavar="N",
@@ -405,30 +464,23 @@ def main():
                            "achieved": fam_work / (fam_ms * 1e-3) / (1e12 if mfma else 1e9)},
                 "by_symbol_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in
                                           sorted(syms.items(), key=lambda kv: -kv[1][0])[:12]}}
-            if mfma and dom.startswith(("gemm_pstag_kernel", "gemm_stag_kernel", "gemm_pgroup", "gemm_p1_kernel")):
-                # What actually paces a 256x128x64 tile loop is the operand stream into LDS, not the matrix pipe: every
-                # 2*256*128*64 FLOP stage (256+128)*64*2 B through the CU's LDS-DMA path.  Its ceiling under this very
-                # access pattern, with NO compute at all, is 63.3 GB/s per CU = 16.2 TB/s (tests/bench_dma_rate.py: 12-16
-                # issuing waves, any ring depth; the guide's 66-73 GB/s per CU is for an L2-resident gather).  Reported
-                # beside the MFMA fraction so that the binding roofline is visible: bytes staged / launch duration.
+            if mfma and dom.startswith(("gemm_pstag_kernel", "gemm_stag_kernel", "gemm_pgroup")):
+                # What paces a 256x128x64 tile loop is the delivery of operand bytes to the CU, not the matrix pipe: every
+                # 2*256*128*64 FLOP take (256+128)*64*2 B.  Ceiling of that delivery under this very access pattern with NO
+                # compute: 66 GB/s per CU = 16.9 TB/s, the same through THREE load paths (LDS-DMA; coalesced global -> VGPR;
+                # global -> VGPR -> ds_write: profiles/r04_fill_paths.json), and it is what the vendor's best kernel reaches
+                # on the largest shapes (1.43 PFLOP/s, profiles/r04_gemm_yardstick.json).  Reported beside the MFMA fraction
+                # so that the binding roofline is visible: bytes staged / launch duration.
                 staged = work / (2.0 * 256 * 128 * 64) * (256 + 128) * 64 * 2
                 res["roofline"]["operand_stream"] = {
-                    "bound": "lds_dma_fill", "achieved": staged / (ms * 1e-3) / 1e9, "peak": 63.3 * 256, "unit": "GB/s",
-                    "frac": staged / (ms * 1e-3) / 1e9 / (63.3 * 256), "bytes_staged_per_launch_avg": staged / cnt,
-                    "note": "tile 256x128x64: 11.7 B staged per kFLOP, so 16.2 TB/s of LDS fill caps this tile shape at "
-                            "1.38 PFLOP/s whatever the loop structure (gemm_p1_kernel, a different structure, runs at the "
-                            "same speed: tests/bench_p1.py); peak = the no-compute fill rate measured with the GEMM's own "
-                            "panel sharing (tests/bench_dma_rate.py)"}
-        pmc = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
-        if "roofline" in res and os.path.exists(pmc):
-            try:  # HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
-                t = json.load(open(pmc))
-                e = t.get("kernels", {}).get(res["roofline"]["kernel"])
-                if e is not None:
-                    res["roofline"]["traffic"] = e["hbm_bytes_per_launch"]
-                    res["roofline"]["traffic_source"] = os.path.relpath(pmc, ROOT) + ": " + t["method"]
-            except Exception:
-                pass
+                    "bound": "cu_operand_delivery", "achieved": staged / (ms * 1e-3) / 1e9, "peak": 66.0 * 256, "unit": "GB/s",
+                    "frac": staged / (ms * 1e-3) / 1e9 / (66.0 * 256), "bytes_staged_per_launch_avg": staged / cnt,
+                    "note": "tile 256x128x64: 11.7 B per kFLOP, so 16.9 TB/s of operand delivery caps this tile shape at "
+                            "1.44 PFLOP/s whatever the loop or load path (profiles/r04_fill_paths.json: LDS-DMA 63-66, "
+                            "global->VGPR 65.8, global->VGPR->LDS 66.1 GB/s per CU, fragment-layout VGPR loads 31-38; "
+                            "profiles/r04_gemm_yardstick.json: hipBLASLt / rocBLAS on the same shapes)"}
+        if "roofline" in res and world == 1 and not args.no_traffic:
+            res["roofline"].update(measure_traffic(res["roofline"]["kernel"]))
         try:
             # Not part of the metric (the distillation MICRO-step, repeated gradient_accumulation_steps times per
             # optimizer step, train.py:336): the fused AdamW + global-norm clip that follows the last micro-step
