@@ -98,6 +98,33 @@ def cpu_baseline(sample_T, threads, n_seq=2):
     return res, sw, tw, batch, out
 
 
+def rccl_choice(path):
+    """What RCCL says it chose, parsed from its own NCCL_DEBUG=INFO log of this rank (None when the run was not started
+    with NCCL_DEBUG=INFO).  TUNING lines read `<bytes> Bytes -> Algo <a> proto <p> time <t>` (algo 0 tree, 1 ring, 2/3
+    collnet, proto 0 LL, 1 LL128, 2 Simple); INIT / GRAPH lines name the transport of every channel (`via P2P/...`,
+    `via SHM`, `via NET`) and the ring / tree channel counts."""
+    import re
+    if not path or not os.path.exists(path):
+        return None
+    txt = open(path, errors="replace").read()
+    algo_names, proto_names = {0: "tree", 1: "ring", 2: "collnet_direct", 3: "collnet_chain"}, {0: "LL", 1: "LL128", 2: "Simple"}
+    picks = {}
+    for m in re.finditer(r"(\d+) Bytes -> Algo (\d+) proto (\d+)", txt):
+        key = (int(m.group(1)), int(m.group(2)), int(m.group(3)))
+        picks[key] = picks.get(key, 0) + 1
+    transports = {}
+    for m in re.finditer(r"via (P2P[/\w]*|SHM[/\w]*|NET[/\w]*|direct shared memory)", txt):
+        transports[m.group(1)] = transports.get(m.group(1), 0) + 1
+    ch = re.search(r"(\d+) coll channels, (\d+) (?:collnet|nvls) channels.*?(\d+) p2p channels", txt)
+    return {"log": path,
+            "collectives": [{"bytes": b, "algo": algo_names.get(a, a), "proto": proto_names.get(pr, pr), "count": n}
+                            for (b, a, pr), n in sorted(picks.items())][:40],
+            "transports": transports, "rings_connected": "Connected all rings" in txt, "trees_connected": "Connected all trees" in txt,
+            "channels": ch.groups() if ch else None,
+            "note": "no `Bytes -> Algo` lines: this RCCL build does not print TUNING decisions, or every collective was a "
+                    "one-rank shortcut" if not picks else None}
+
+
 def measure_traffic(symbol, timeout_s=170):
     """`roofline.traffic`, MEASURED in this very run: two child runs of this script under
     `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, nothing else traced; 2 steps on one stream), the
@@ -115,6 +142,8 @@ def measure_traffic(symbol, timeout_s=170):
         from pmc_summary import per_kernel, symbol as sym_of
         if shutil.which("rocprofv3") is None:
             raise RuntimeError("rocprofv3 not on PATH")
+        if any("rocprof" in os.environ.get(k, "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB")):
+            raise RuntimeError("this process already runs under a profiler: no nested rocprofv3")
         got = {}
         for ctr, mul in (("FETCH_SIZE", 2048.0), ("WRITE_SIZE", 1024.0)):
             d = tempfile.mkdtemp(prefix="sd_pmc_", dir="/tmp")
@@ -211,6 +240,12 @@ def main():
         if args.single_device:
             local_rank = 0
         torch.cuda.set_device(local_rank)
+        # With NCCL_DEBUG=INFO set by whoever launches the run, keep RCCL's log in a file per rank so that rank 0 can report
+        # WHICH algorithm / protocol / transport RCCL chose (`comm.rccl_choice`): the first real 8-GPU run then tells a ring
+        # from a direct all-reduce without a second run.
+        if args.backend == "nccl" and os.environ.get("NCCL_DEBUG", "").upper() in ("INFO", "TRACE"):
+            os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,TUNING,GRAPH")
+            os.environ.setdefault("NCCL_DEBUG_FILE", "/tmp/sd_rccl_rank%d.log" % rank)
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -386,7 +421,7 @@ def main():
                 "buckets": bl, "comm_stream_busy_ms_per_step": round(sum(b["ms"] for b in bl), 4),
                 "exposed_ms_per_step": round(sum(exposed) / max(1, len(exposed)), 4) if exposed else None,
                 "bytes_per_step": sum(b["MB"] for b in bl) * 1e6, "every_gradient_element_reduced_once": covered,
-                "stats": dict(reducer.stats)}
+                "stats": dict(reducer.stats), "rccl_choice": rccl_choice(os.environ.get("NCCL_DEBUG_FILE"))}
     if multi:
         tmax = torch.tensor([dt], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -519,7 +554,7 @@ def main():
                 got = loss_fn.forward_rows(student(input_ids=gb["input_ids"], attention_mask=gb["attention_mask"],
                                                    logit_rows=rows).logits, row_labels, teacher_top_k_v=tv,
                                            teacher_top_k_i=ti)
-                g4 = [float(x) for x in got]
+                g4 = [float(x.detach()) for x in got]
                 w4 = [float(cout[k]) for k in ("total", "task", "distill", "teacher")]
                 res["loss_match"] = {"hip_bf16": g4, "oracle_fp32": w4, "rel_err_total": abs(g4[0] - w4[0]) / abs(w4[0]),
                                      "tolerance": 2e-2, "sample": "the cpu_baseline sample: same weights (bf16-rounded), same "

@@ -12,15 +12,15 @@ out=gpurun_out/prof_$tag
 mkdir -p $out
 export TMPDIR=/tmp
 root=$(pwd)
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/default -o run -- python3 $root/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $out/default.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/default -o run -- python3 $root/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-traffic > $out/default.log 2>&1
 echo "[profile] default done"
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/serial -o run -- python3 $root/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-prof --no-overlap > $out/serial.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/serial -o run -- python3 $root/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-prof --no-overlap --no-traffic > $out/serial.log 2>&1
 echo "[profile] serial done"
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -o run -- python3 $root/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-prof --no-overlap > $out/fetch.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -o run -- python3 $root/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-prof --no-overlap --no-traffic > $out/fetch.log 2>&1
 echo "[profile] fetch done"
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -o run -- python3 $root/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-prof --no-overlap > $out/write.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -o run -- python3 $root/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-prof --no-overlap --no-traffic > $out/write.log 2>&1
 echo "[profile] write done"
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $out/mfma -o run -- python3 $root/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-prof --no-overlap > $out/mfma.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $out/mfma -o run -- python3 $root/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-prof --no-overlap --no-traffic > $out/mfma.log 2>&1
 echo "[profile] mfma done"
 find $out -name "*kernel_stats.csv" -o -name "*counter_collection.csv" | sort
 # keep the merge-back under gpurun's 64 MiB: traces are not needed, only the stats / counter tables

@@ -17,10 +17,18 @@ Which of the two RCCL picks for ``all_reduce`` is its own choice, so both collec
 ``all_gather_into_tensor`` on the same slice) -- together with the bucket size (``layers_per_bucket``: 31.5 MB per layer
 for the 0.6B student) and a per-bucket timing mode (``timing=True``: events on the communication stream + the exposed
 wait in ``finish``), so that a run on real links can tell them apart (``bench.py --comm-algo / --layers-per-bucket``).
+
+Status of the two forms: ``allreduce`` is the default and the only one that has run with more than one rank anywhere
+(gloo ranks on CPU / one GPU; the RCCL path itself only as a one-rank rehearsal).  ``rs_ag`` is EXPERIMENTAL until
+``bench.py``'s ``grad_sync_ok`` and a parameter checksum have passed on a real multi-GPU node: its in-place
+reduce-scatter into a slice of its own input, the AVG semantics of ``reduce_scatter_tensor`` and the bit-identity of the
+gathered gradients across ranks are unverified at W > 1.  A bucket whose size does not divide by W cannot use it and
+falls back to ``all_reduce`` -- loudly (one warning per bucket size, counted in ``stats["rs_ag_fallbacks"]``).
 """
 from __future__ import annotations
 
 import contextlib
+import warnings
 
 import torch
 import torch.distributed as dist
@@ -68,6 +76,7 @@ class FlatGradAllReduce:
         # rehearsal of the N > 1 call sequence on a one-GPU box (bench.py --force-dist, tests/test_00_gpu_rccl1.py)
         self.active = self.world > 1 or (rehearse_single_rank and dist.is_initialized())
         self.algo = algo
+        self._warned_sizes = set()
         self.timing = timing
         self._timed = []      # (stage, numel, start event, end event) of the current step
         self._exposed = None  # (event before, event after) the main stream's wait for the communication stream
@@ -196,6 +205,12 @@ class FlatGradAllReduce:
             dist.reduce_scatter_tensor(mine, chunk, op=dist.ReduceOp.AVG, group=self.group)
             dist.all_gather_into_tensor(chunk, mine, group=self.group)
         else:
+            if self.algo == "rs_ag":  # asked for the direct form, cannot have it: say so (once per bucket size)
+                self.stats["rs_ag_fallbacks"] = self.stats.get("rs_ag_fallbacks", 0) + 1
+                if chunk.numel() not in self._warned_sizes:
+                    self._warned_sizes.add(chunk.numel())
+                    warnings.warn(f"FlatGradAllReduce: algo='rs_ag' but a bucket of {chunk.numel()} elements does not divide "
+                                  f"by the world size {W}: this bucket uses all_reduce (ring or direct is then RCCL's choice)")
             dist.all_reduce(chunk, op=dist.ReduceOp.AVG, group=self.group)
 
     def _tick(self):
@@ -239,7 +254,8 @@ def attach(model, group=None, layers_per_bucket=None, split_embedding=True, algo
            rehearse_single_rank=False):
     """Wire the backward stage callback of a flat-gradient model (HipQwen3ForCausalLM) to overlapped all-reduces.
     ``layers_per_bucket`` / ``algo`` default to the environment variables SD_LAYERS_PER_BUCKET (1) / SD_COMM_ALGO
-    ("allreduce"), so a ``torchrun scripts/train.py`` launch can A/B them without code changes."""
+    ("allreduce"; "rs_ag" is EXPERIMENTAL, see the module docstring), so a ``torchrun scripts/train.py`` launch can A/B
+    them without code changes."""
     import os
     layers_per_bucket = int(os.environ.get("SD_LAYERS_PER_BUCKET", "1")) if layers_per_bucket is None else layers_per_bucket
     algo = os.environ.get("SD_COMM_ALGO", "allreduce") if algo is None else algo

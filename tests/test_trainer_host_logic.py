@@ -199,3 +199,45 @@ def test_tokens_per_second_is_logged_by_the_real_loop():
     # the sub-loss logs of train.py:107-114 are untouched
     sub = [d for d in tr.state.log_history if "student_loss" in d]
     assert sub and all("tokens_per_second" not in d for d in sub)
+
+
+def test_rs_ag_fallback_is_loud_and_counted(monkeypatch):
+    """algo='rs_ag' on a bucket that does not divide by the world size falls back to all_reduce with ONE
+    warning per bucket size and a count in stats -- never silently."""
+    import warnings
+    from speech_distill_amd import ddp
+    red = ddp.FlatGradAllReduce.__new__(ddp.FlatGradAllReduce)
+    red.algo, red.world, red.group, red.stats, red._warned_sizes = "rs_ag", 3, None, {}, set()
+    calls = []
+    monkeypatch.setattr(ddp.dist, "all_reduce", lambda t, op=None, group=None: calls.append(t.numel()))
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        red._reduce_on_stream(torch.zeros(8))
+        red._reduce_on_stream(torch.zeros(8))
+        red._reduce_on_stream(torch.zeros(16))
+    assert calls == [8, 8, 16] and red.stats["rs_ag_fallbacks"] == 3
+    assert len([x for x in w if "does not divide" in str(x.message)]) == 2  # sizes 8 and 16, once each
+
+
+def test_rccl_choice_parser_reads_a_debug_log(tmp_path):
+    """bench.py's `comm.rccl_choice` from an NCCL_DEBUG=INFO log (format of NCCL/RCCL 2.2x)."""
+    import importlib.util
+    import os
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    log = tmp_path / "rccl.log"
+    log.write_text(
+        "host:1:1 [0] NCCL INFO Channel 00/0 : 0[0] -> 1[1] via P2P/IPC\\n"
+        "host:1:1 [0] NCCL INFO Channel 01/0 : 0[0] -> 1[1] via P2P/IPC\\n"
+        "host:1:1 [0] NCCL INFO Connected all rings\\nhost:1:1 [0] NCCL INFO Connected all trees\\n"
+        "host:1:1 [0] NCCL INFO 16 coll channels, 0 collnet channels, 0 nvls channels, 16 p2p channels, 2 p2p channels per peer\\n"
+        "host:1:1 [0] NCCL INFO AllReduce: 33030144 Bytes -> Algo 1 proto 2 time 412.5\\n"
+        "host:1:1 [0] NCCL INFO AllReduce: 33030144 Bytes -> Algo 1 proto 2 time 412.5\\n"
+        "host:1:1 [0] NCCL INFO AllReduce: 4096 Bytes -> Algo 0 proto 0 time 8.1\\n")
+    r = bench.rccl_choice(str(log))
+    assert r["transports"] == {"P2P/IPC": 2} and r["rings_connected"] and r["trees_connected"]
+    assert {"bytes": 33030144, "algo": "ring", "proto": "Simple", "count": 2} in r["collectives"]
+    assert {"bytes": 4096, "algo": "tree", "proto": "LL", "count": 1} in r["collectives"]
+    assert bench.rccl_choice(None) is None and bench.rccl_choice(str(tmp_path / "absent")) is None
