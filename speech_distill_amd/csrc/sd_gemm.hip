@@ -1618,7 +1618,12 @@ int dispatch(const void* A, const void* B, void* C, const void* R, float* slabs,
     else if (tiles128 >= 256) { bm = 128; nst = 3; }
     else { bm = 64; nst = blocks64 <= 320 ? 4 : 3; }
   } else if (!ta) {  // NN: dX = dY . W (weights cold)
-    if (splits > 1 || tiles256 >= 192) { bm = 256; nst = 9; }
+    // round 4 (tests/bench_tune.py, profiles/r04_gemm_tune.json): the dX GEMMs with a heavy fused epilogue (EPI 5: SwiGLU
+    // backward, 50 MB of gate|up / d(gate|up) per launch; EPI 6: delta) and at least 1.5 rounds of 128x128 tiles run 3-6 %
+    // faster on TWO co-resident 128x128 workgroups per CU (2-stage ring, 64 KiB each: one's epilogue beside the other's K
+    // loop) than on one 256x128 workgroup: down dX 29.6 -> 28.7 us at 2 048 tokens, 86.8 -> 83.2 / 53.1 -> 50.2 us at 8 192.
+    if (splits == 1 && (epi_kind == 5 || epi_kind == 6) && tiles128 >= 384) { bm = 128; nst = 2; }
+    else if (splits > 1 || tiles256 >= 192) { bm = 256; nst = 9; }
     else if (tiles128 >= 256) { bm = 128; nst = 3; }
     else { bm = 64; nst = 3; }
   } else {  // TN: dW = dY^T . X (two warm activations)

@@ -342,7 +342,7 @@ def test_gemm_persistent_swiglu(ops):
     assert torch.equal(act3, act_ref) and torch.equal(gu3, gu_ref)
 
 
-@pytest.mark.parametrize("bm,nst", [(0, 0), (64, 3), (128, 3), (256, 9)])
+@pytest.mark.parametrize("bm,nst", [(0, 0), (64, 3), (128, 2), (128, 3), (256, 9)])
 def test_gemm_swiglu_bwd_epilogue_equals_the_separate_kernels(ops, bm, nst):
     """down-projection dX GEMM + SwiGLU backward in its epilogue == sd_gemm_bf16 (NN) + sd_swiglu_bwd, bit for bit."""
     g = torch.Generator().manual_seed(17)
@@ -420,7 +420,7 @@ def test_persistent_weight_gradient_kernels_under_a_cu_budget(ops, budget, monke
         _lib.debug_set("gemm.cu_budget", 0)
 
 
-@pytest.mark.parametrize("M,T,Hq,H", [(2048, 512, 16, 1024), (300, 100, 2, 256)])
+@pytest.mark.parametrize("M,T,Hq,H", [(2048, 512, 16, 1024), (4096, 512, 16, 1024), (300, 100, 2, 256)])
 def test_gemm_odx_delta_epilogue(ops, M, T, Hq, H):
     """o-projection dX with delta = rowsum(dO * O) per (token, head) in the epilogue: d_ao bit-identical to the plain NN
     GEMM, delta equal to the fp32 row sums of the bf16 products (what attn_delta_kernel computes), ragged M."""
