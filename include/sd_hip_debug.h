@@ -18,6 +18,7 @@
  *   gemm.tn_stag_min           1024     least number of 256x128 tiles for the staggered kernels on a TN (dW) GEMM
  *   gemm.splitk_min_kt         96       least K/64 for sd_gemm_splitk_plan to split
  *   gemm.splitk_min_slice      24       least K/64 per slice (clamped to >= 1)
+ *   gemm.no_table              0        ignore the measured shape -> variant table (csrc/sd_gemm_table.inc): heuristic only
  *   model.fuse_student_swiglu  0        SwiGLU in the gate|up GEMM epilogue also when gate|up is kept for the backward
  *   model.overlap_mask         31       sd_qwen3_backward: bit0 lm_head dW, bit1 gain reduces, bit2 attention dQ on the side
  *                                       stream, bit3 grouped per-layer dW, bit4 one batched gain reduce per layer

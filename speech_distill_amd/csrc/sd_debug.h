@@ -13,6 +13,7 @@ struct SdDebug {
   int gemm_group_m = 0;
   int gemm_tn_stag_min = 1024;
   int gemm_splitk_min_kt = 96, gemm_splitk_min_slice = 24;
+  int gemm_no_table = 0;  // ignore the measured shape -> variant table (sd_gemm_table.inc)
   // sd_model.hip
   int model_fuse_student_swiglu = 0;
   int model_overlap_mask = 31;  // bit0 lm_head dW, bit1 gain reduces, bit2 attention dQ, bit3 grouped per-layer dW, bit4 batched gain reduce

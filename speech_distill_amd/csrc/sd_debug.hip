@@ -22,6 +22,7 @@ const Key kKeys[] = {
     {"gemm.tn_stag_min", &SdDebug::gemm_tn_stag_min},
     {"gemm.splitk_min_kt", &SdDebug::gemm_splitk_min_kt},
     {"gemm.splitk_min_slice", &SdDebug::gemm_splitk_min_slice},
+    {"gemm.no_table", &SdDebug::gemm_no_table},
     {"model.fuse_student_swiglu", &SdDebug::model_fuse_student_swiglu},
     {"model.overlap_mask", &SdDebug::model_overlap_mask},
     {"topk.nt", &SdDebug::topk_nt},

@@ -386,26 +386,30 @@ __global__ __launch_bounds__(256) void embedding_fwd_kernel(const int64_t* __res
   for (int c = lane_id() * 8; c < H; c += 512) *(bf16x8*)(x + (long)row * H + c) = *(const bf16x8*)(E + id * H + c);
 }
 
-// The same lookup, leaving per row and 128-column tile the sum of squares of the row (fp32 [M, H/128]): the statistic of the
+// The same lookup, leaving per row and 128-column tile the sum of squares of the row (fp32, tile-major [H/128][M]): the statistic of the
 // FIRST decoder layer's input norm when that norm is folded into the q|k|v projection (sd_gemm_qkv_rope_rs).  A lane's 8
 // columns of chunk i lie in tile (lane >> 4) + 4 i, so one 16-lane DPP row sum is one tile.
 __global__ __launch_bounds__(256) void embedding_fwd_ssq_kernel(const int64_t* __restrict__ ids, const bf16* __restrict__ E,
                                                                 bf16* __restrict__ x, float* __restrict__ ssq, int M, int H,
                                                                 int V) {
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= M) return;
-  long id = ids[row];
-  id = id < 0 ? 0 : (id >= V ? V - 1 : id);
-  const int lane = lane_id(), nt = H >> 7;
-  for (int i = 0; i * 512 < H; ++i) {  // H % 512 == 0: every lane is active in every trip (DPP needs the full row)
-    const int c = lane * 8 + i * 512;
-    const bf16x8 v = *(const bf16x8*)(E + id * H + c);
-    *(bf16x8*)(x + (long)row * H + c) = v;
-    float ss = 0.f;
+  // a workgroup takes 16 consecutive rows (a wave 4 of them): the 64-byte lines of the tile-major ssq [H/128][M] it
+  // writes are its own
+  const int lane = lane_id();
+  for (int rr = 0; rr < 4; ++rr) {
+    const int row = blockIdx.x * 16 + (threadIdx.x >> 6) * 4 + rr;
+    if (row >= M) return;  // wave-uniform
+    long id = ids[row];
+    id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+    for (int i = 0; i * 512 < H; ++i) {  // H % 512 == 0: every lane is active in every trip (DPP needs the full row)
+      const int c = lane * 8 + i * 512;
+      const bf16x8 v = *(const bf16x8*)(E + id * H + c);
+      *(bf16x8*)(x + (long)row * H + c) = v;
+      float ss = 0.f;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; ss += f * f; }
-    ss = row16_sum(ss);
-    if ((lane & 15) == 0) ssq[(long)row * nt + (lane >> 4) + 4 * i] = ss;
+      for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; ss += f * f; }
+      ss = row16_sum(ss);
+      if ((lane & 15) == 0) ssq[(long)((lane >> 4) + 4 * i) * M + row] = ss;
+    }
   }
 }
 
@@ -691,7 +695,7 @@ extern "C" int sd_embedding_fwd_ssq(const int64_t* ids, const void* E, void* x, 
   if (M <= 0 || (H & 7) || !ssq_out) return SD_ERR_SHAPE;
   if ((H % 512) || H / 128 > 16) return SD_ERR_UNSUPPORTED;
   SdProfScope prof(SD_K_EMBED, 4.0 * M * H, ST);
-  hipLaunchKernelGGL(embedding_fwd_ssq_kernel, dim3((M + 3) / 4), dim3(256), 0, ST, ids, (const bf16*)E, (bf16*)x, ssq_out, M,
+  hipLaunchKernelGGL(embedding_fwd_ssq_kernel, dim3((M + 15) / 16), dim3(256), 0, ST, ids, (const bf16*)E, (bf16*)x, ssq_out, M,
                      H, V);
   SD_CHECK_LAUNCH();
   return 0;

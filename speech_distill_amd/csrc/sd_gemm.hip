@@ -169,9 +169,13 @@ SD_DEV bf16x8 load_frag32(const char* tile, int row16_base, int lane) {  // 16 r
 //   Folded RMSNorm (round 4; the frozen teacher, HF:59-64 + the projection behind it): the norm's gain is folded into the
 //   weight rows once at load (W' = W.diag(g)), so y = rstd (.) (x W'^T) and the norm needs no pass of its own:
 //     ssq_out (EPI 1): the residual epilogue also leaves, per row and 128-column tile, the sum of squares of the bf16
-//             values it stores: ssq_out[row * ssq_n + tile] (fp32; ssq_n = N / 128 <= 16);
+//             values it stores: ssq_out[tile * M + row] (fp32, TILE-major [ssq_n][M], ssq_n = N / 128 <= 16: a 64-byte
+//             line holds 16 rows of ONE tile, i.e. is written by one workgroup -- row-major, 16 workgroups on different
+//             XCDs each wrote 4 bytes of every line and the launch took +10 % at 32 768 rows);
 //     ssq_in  (EPI 3 / 4): the consumer sums a row's ssq_n partials in a fixed order, rstd = rsqrt(sum * inv_h + eps_rs),
-//             and scales the accumulator row by it before anything else happens to it.
+//             and scales the accumulator row by it before anything else happens to it.  The partials are FETCHED before
+//             the K loop and only USED in the epilogue: a use in the prologue made every workgroup wait for them before
+//             its first DMA piece went out (+11 us per tile with the memory system busy, config 5).
 struct EpiArgs {
   bf16* out2;
   long ld2;
@@ -194,7 +198,7 @@ struct EpiPre {
   bf16x8 a[(EPI == 1 || EPI == 4 || EPI == 5 || EPI == 6) ? IT : 1];
   bf16x8 b[(EPI == 4 || EPI == 5) ? IT : 1];
   bf16x8 gain;
-  float rs[(EPI == 3 || EPI == 4) ? IT : 1];  // row scale of the folded RMSNorm (1 when ea.ssq_in == nullptr)
+  float rs[(EPI == 3 || EPI == 4) ? IT : 1];  // folded RMSNorm: this thread's partial sum of squares of its row (raw)
 };
 
 template <int EPI, int BM, int NTHR>
@@ -229,20 +233,22 @@ SD_DEV void epi_preload(EpiPre<EPI, BM, NTHR>& pre, const bf16* R, const EpiArgs
     if constexpr (EPI == 4) pre.gain = *(const bf16x8*)((tn < ea.Hq ? ea.g0 : ea.g1) + (threadIdx.x & 15) * 8);
   }
   if constexpr (EPI == 3 || EPI == 4) {
-    // the 16 threads of a row (one DPP row) fetch one partial each and add them in the fixed butterfly order
+    // the 16 threads of a row (one DPP row) fetch one partial each; they are summed in the epilogue (row_scale)
 #pragma unroll
     for (int it = 0; it < BM * 16 / NTHR; ++it) {
-      float rs = 1.f;
+      float part = 0.f;
       if (ea.ssq_in) {  // kernel-uniform
         const int q = it * NTHR + threadIdx.x;
         const int gm = m0 + (q >> 4), oc = q & 15;
-        const float part = (oc < ea.ssq_n) ? ea.ssq_in[(long)(gm < M ? gm : M - 1) * ea.ssq_n + oc] : 0.f;
-        rs = rsqrtf(row16_sum(part) * ea.inv_h + ea.eps_rs);
+        if (oc < ea.ssq_n) part = ea.ssq_in[(long)oc * M + (gm < M ? gm : M - 1)];
       }
-      pre.rs[it] = rs;
+      pre.rs[it] = part;
     }
   }
 }
+
+// rstd of this thread's row from the 16 partials its DPP row holds (fixed butterfly order); every lane must be active
+SD_DEV float row_scale(float part, const EpiArgs& ea) { return rsqrtf(row16_sum(part) * ea.inv_h + ea.eps_rs); }
 
 template <int EPI, int BM, int NTHR>
 SD_DEV void write_out(const float* cs, bf16* C, const EpiPre<EPI, BM, NTHR>& pre, float* slabs, const EpiArgs& ea, int M,
@@ -269,8 +275,9 @@ SD_DEV void write_out(const float* cs, bf16* C, const EpiPre<EPI, BM, NTHR>& pre
       const f32x4 uhi = *(const f32x4*)(cs + m * 128 + (((2 * oc2 + 1) ^ (m & 15)) << 2));
       float u[8] = {ulo[0], ulo[1], ulo[2], ulo[3], uhi[0], uhi[1], uhi[2], uhi[3]};
       if (ea.ssq_in) {
+        const float rsc = row_scale(pre.rs[it], ea);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { v[e] *= pre.rs[it]; u[e] *= pre.rs[it]; }
+        for (int e = 0; e < 8; ++e) { v[e] *= rsc; u[e] *= rsc; }
       }
       const int col = tn * 64 + oc * 8;
       if (oc < 8 && gm < M && col < ea.I) {
@@ -320,8 +327,9 @@ SD_DEV void write_out(const float* cs, bf16* C, const EpiPre<EPI, BM, NTHR>& pre
     } else if constexpr (EPI == 4) {
       bf16x8 raw;
       if (ea.ssq_in) {
+        const float rsc = row_scale(pre.rs[it], ea);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] *= pre.rs[it];
+        for (int e = 0; e < 8; ++e) v[e] *= rsc;
       }
 #pragma unroll
       for (int e = 0; e < 8; ++e) raw[e] = (bf16)v[e];
@@ -358,7 +366,7 @@ SD_DEV void write_out(const float* cs, bf16* C, const EpiPre<EPI, BM, NTHR>& pre
 #pragma unroll
           for (int e = 0; e < 8; ++e) { const float f = ok ? (float)o[e] : 0.f; ss += f * f; }
           ss = row16_sum(ss);
-          if (oc == 0 && gm < M) ea.ssq_out[(long)gm * ea.ssq_n + tn] = ss;
+          if (oc == 0 && gm < M) ea.ssq_out[(long)tn * M + gm] = ss;
         }
       }
     }
@@ -753,8 +761,8 @@ __global__ __launch_bounds__(768) void gemm_pstag_kernel(const bf16* __restrict_
     __builtin_amdgcn_s_barrier();
     int nxt = DEPTH;
     // Folded RMSNorm (EPI 3 with ea.ssq_in): the 4 x 64 producer lanes are the 256 rows of the tile being COMPUTED.  In the
-    // tile's first K-step each lane fetches its row's partial sums of squares (4 x 16 B, one 64-byte segment per lane:
-    // 4 KiB contiguous per wave) AHEAD of that step's DMA pieces, so the step's ordinary counted wait covers them (they are
+    // tile's first K-step each lane fetches its row's partial sums of squares (16 loads of 4 B, each 256 contiguous bytes
+    // per wave) AHEAD of that step's DMA pieces, so the step's ordinary counted wait covers them (they are
     // older than the pieces it leaves in flight); then it writes rstd into the LDS table of the tile's parity (the store
     // patches, idle in this epilogue).  The compute waves read it at the end of the tile, nk K-steps of barriers later.
     [[maybe_unused]] int ct = 0, ck = 0;  // tile / K-step of the step being computed
@@ -763,7 +771,7 @@ __global__ __launch_bounds__(768) void gemm_pstag_kernel(const bf16* __restrict_
       // then everything up to K-step g+1 has landed
       SD_STAMP_DUMP(g);
       SD_STAMP(g, 0);
-      [[maybe_unused]] f32x4 sq[4];
+      [[maybe_unused]] float sq[16];
       bool fold_now = false;
       if constexpr (EPI == 3) {
         fold_now = ea.ssq_in != nullptr && ck == 0;  // workgroup-uniform
@@ -772,10 +780,10 @@ __global__ __launch_bounds__(768) void gemm_pstag_kernel(const bf16* __restrict_
           origin(ct, tm, tn);
           int gm = tm * BM + pw * 64 + lane;
           gm = gm < M ? gm : M - 1;
-          const int nch = (ea.ssq_n + 3) >> 2;  // f32x4 chunks of a row's partials (ssq_n is a multiple of 4)
-          const float* src = ea.ssq_in + (long)gm * ea.ssq_n;
+          // tile-major partials: one load per tile, 64 consecutive rows per wave-instruction (256 B); always 16 loads
+          // (tiles past ssq_n re-read the last one and count as 0) so that the step's counted wait sees a fixed number
 #pragma unroll
-          for (int c = 0; c < 4; ++c) sq[c] = *(const f32x4*)(src + 4 * (c < nch ? c : nch - 1));
+          for (int t = 0; t < 16; ++t) sq[t] = ea.ssq_in[(long)(t < ea.ssq_n ? t : ea.ssq_n - 1) * M + gm];
         }
       }
       pf_issue(smem + nxt * STAGE);
@@ -784,11 +792,15 @@ __global__ __launch_bounds__(768) void gemm_pstag_kernel(const bf16* __restrict_
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DEPTH - 1) * LOADS) : "memory");
       if constexpr (EPI == 3) {
         if (fold_now) {
-          // the same balanced tree as row16_sum over 16 lanes (epi_preload of the one-tile kernels): bit-identical rstd
-          const int nch = (ea.ssq_n + 3) >> 2;
+          // the same balanced tree as row16_sum over 16 lanes (row_scale in the one-tile kernels): bit-identical rstd
           float qd[4];
 #pragma unroll
-          for (int c = 0; c < 4; ++c) qd[c] = (c < nch) ? (sq[c][0] + sq[c][1]) + (sq[c][2] + sq[c][3]) : 0.f;
+          for (int c = 0; c < 4; ++c) {
+            float p4[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) p4[e] = (4 * c + e < ea.ssq_n) ? sq[4 * c + e] : 0.f;
+            qd[c] = (p4[0] + p4[1]) + (p4[2] + p4[3]);
+          }
           const float tot = (qd[0] + qd[1]) + (qd[2] + qd[3]);
           ((float*)(smem + NST * STAGE + (ct & 1) * 1024))[pw * 64 + lane] = rsqrtf(tot * ea.inv_h + ea.eps_rs);
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1479,7 +1491,7 @@ thread_local bool g_skip_reduce = false;  // set by sd_gemm_bf16_splitk_partial 
 
 template <int BM, int NST, bool TA, bool TB>
 int launch(const void* A, const void* B, void* C, const void* R, float* slabs, int splits, int M, int N, int K, long lda,
-           long ldb, long ldc, long ldr, int epi_kind, const EpiArgs& ea, hipStream_t st) {
+           long ldb, long ldc, long ldr, int epi_kind, const EpiArgs& ea, hipStream_t st, int tflags) {
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   const int kt_all = (K + BK - 1) / BK;
   const int per = (kt_all + splits - 1) / splits;
@@ -1497,15 +1509,17 @@ int launch(const void* A, const void* B, void* C, const void* R, float* slabs, i
       return 0;
     return cus & ~7;
   }();
-  const int persist_grid = g_sd_debug.gemm_no_persist ? 0 : all_cus;
-  const bool p256_ok = !g_sd_debug.gemm_no_p256;
+  // tflags: what the measured table (sd_gemm_table.inc) asks for this very shape: 1 no persistent kernel, 2 no 256x256
+  // kernel, 4 the 256x256 kernel whatever the tile count
+  const int persist_grid = (g_sd_debug.gemm_no_persist || (tflags & 1)) ? 0 : all_cus;
+  const bool p256_ok = !g_sd_debug.gemm_no_p256 && !(tflags & 2);
   const bool p256_pair = !g_sd_debug.gemm_p256_unpaired;
   // Measured (tests/bench_p256.py, MI355X): the 256 x 256 kernel ties the 256 x 128 one on the lm_head class (544 vs
   // 557 us student, 924 vs 929 us teacher) and loses on gate|up (114 vs 93 us teacher, 37.6 vs 36.3 us student): both
   // settle at ~0.9 us per staged K-step whatever the bytes of the step, i.e. the loop is paced by the latency of the
   // operand stream at the LDS-limited prefetch depth, not by L2 -> LDS bandwidth per FLOP.  So only the vocabulary-wide
   // GEMMs take it.  gemm.p256_min_tiles (sd_hip_debug.h) lowers the threshold for measurements / tests.
-  const int p256_min_tiles = g_sd_debug.gemm_p256_min_tiles;
+  const int p256_min_tiles = (tflags & 4) ? 1 : g_sd_debug.gemm_p256_min_tiles;
   const int gm_env = g_sd_debug.gemm_group_m;
   int gm = gm_env > 0 ? gm_env : (BM == 256 ? 4 : 8);
   if (gm > tiles_m) gm = tiles_m;
@@ -1590,6 +1604,11 @@ int launch(const void* A, const void* B, void* C, const void* R, float* slabs, i
   return 0;
 }
 
+struct GemmTableEntry { int ta, tb, epi, M, N, K, bm, nst, flags; };
+const GemmTableEntry kGemmTable[] = {
+#include "sd_gemm_table.inc"
+};
+
 int check_args(const void* A, const void* B, const void* C, const void* R, int M, int N, int K, int64_t lda, int64_t ldb,
                int64_t ldc, int64_t ldr, int trans_a, int trans_b) {
   if (M <= 0 || N <= 0 || K <= 0) return SD_ERR_SHAPE;
@@ -1632,6 +1651,18 @@ int dispatch(const void* A, const void* B, void* C, const void* R, float* slabs,
     else if (tiles128 >= 320) { bm = 128; nst = 2; }
     else { bm = 64; nst = blocks64 <= 320 ? 3 : 2; }
   }
+  // Dispatch by measurement (round 4): the GEMM calls of the distillation step at the BASELINE config 2 / 4 / 5 shapes were
+  // timed under every variant (tests/bench_tune.py -> profiles/r04_gemm_tune.json -> scripts/make_gemm_table.py); where a
+  // variant beat the heuristic above by >= 2 % the table names it.  Any other shape keeps the heuristic.
+  int tflags = 0;
+  if (!g_sd_debug.gemm_no_table && !g_sd_debug.gemm_force_bm) {
+    const int key_epi = epi_kind ? epi_kind : (slabs ? 2 : (R ? 1 : 0));
+    for (const GemmTableEntry& e : kGemmTable)
+      if (e.M == M && e.N == N && e.K == K && e.ta == ta && e.tb == tb && e.epi == key_epi) {
+        if (e.bm) { bm = e.bm; nst = e.nst; tflags = e.flags; }
+        break;
+      }
+  }
   if (g_sd_debug.gemm_force_bm) { bm = g_sd_debug.gemm_force_bm; nst = g_sd_debug.gemm_force_nst; }
   // the staggered kernel only has the descriptor staging path
   bool stag_ok = !g_sd_debug.gemm_checked_staging && (ta || tb || (K % BK) == 0) &&
@@ -1641,7 +1672,7 @@ int dispatch(const void* A, const void* B, void* C, const void* R, float* slabs,
   SdProfScope prof(ta ? SD_K_GEMM_TN : (tb ? SD_K_GEMM_NN : ((bm == 256 && nst == 9) ? SD_K_GEMM_NT_STAG : SD_K_GEMM_NT)),
                    2.0 * M * N * K, st);
 #define SD_GO(BM_, NST_, TA_, TB_) \
-  return launch<BM_, NST_, TA_, TB_>(A, B, C, R, slabs, splits, M, N, K, lda, ldb, ldc, ldr, epi_kind, ea, st)
+  return launch<BM_, NST_, TA_, TB_>(A, B, C, R, slabs, splits, M, N, K, lda, ldb, ldc, ldr, epi_kind, ea, st, tflags)
 #define SD_PICK(TA_, TB_)                                   \
   do {                                                      \
     if (bm == 256 && nst == 9 && stag_ok) SD_GO(256, 9, TA_, TB_); \
@@ -1808,7 +1839,7 @@ extern "C" int sd_gemm_odx_delta(const void* dy, const void* wo, void* d_ao, con
 // weight rows of the projection behind it, its row statistic travels as per-tile partial sums of squares [M, K / 128].
 static bool ssq_shape_ok(int K) { return K > 0 && (K % 128) == 0 && K / 128 <= 16 && ((K / 128) % 4) == 0; }
 
-// C [M,N] = A [M,K] . B [N,K]^T + R, and ssq_out [M, N/128] = per 128-column tile sums of squares of the stored bf16 C
+// C [M,N] = A [M,K] . B [N,K]^T + R, and ssq_out [N/128, M] (tile-major) = per 128-column tile sums of squares of the stored bf16 C
 extern "C" int sd_gemm_bf16_ssq(const void* A, const void* B, void* C, const void* R, float* ssq_out, int M, int N, int K,
                                 int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, void* stream) {
   if (int e = check_args(A, B, C, R, M, N, K, lda, ldb, ldc, ldr, 0, 0)) return e;
@@ -1822,7 +1853,7 @@ extern "C" int sd_gemm_bf16_ssq(const void* A, const void* B, void* C, const voi
 
 // gate|up projection with SwiGLU fused into the epilogue (HF:81-83): act [M,I] = silu(x Wg^T) * (x Wu^T);
 // wgu = [gate rows | up rows] ([2I,K], torch layout); gu_out [M,2I] (gate | up, for the backward) may be NULL.
-// ssq != NULL: x is the UN-normalised row, wgu carries the norm's gain, ssq [M, K/128] its partial sums of squares.
+// ssq != NULL: x is the UN-normalised row, wgu carries the norm's gain, ssq [K/128, M] its partial sums of squares.
 static int gemm_swiglu_impl(const void* x, const void* wgu, void* gu_out, void* act_out, const float* ssq, float eps, int M,
                             int I, int K, void* stream) {
   if (M <= 0 || I <= 0 || K <= 0 || (I % 64) || (K % BK)) return SD_ERR_UNSUPPORTED;
@@ -1855,7 +1886,7 @@ extern "C" int sd_gemm_qkv_rope(const void* x, const void* wqkv, void* qkv_out, 
                                 int Hkv, int K, float eps, void* stream) {
   return gemm_qkv_rope_impl(x, wqkv, qkv_out, qk_out, q_gain, k_gain, cos_tab, sin_tab, nullptr, M, T, Hq, Hkv, K, eps, stream);
 }
-// ssq [M, K/128]: x is the UN-normalised row and wqkv carries the input norm's gain (see sd_gemm_bf16_ssq)
+// ssq [K/128, M]: x is the UN-normalised row and wqkv carries the input norm's gain (see sd_gemm_bf16_ssq)
 extern "C" int sd_gemm_qkv_rope_rs(const void* x, const void* wqkv, void* qkv_out, void* qk_out, const void* q_gain,
                                    const void* k_gain, const void* cos_tab, const void* sin_tab, const float* ssq, int M,
                                    int T, int Hq, int Hkv, int K, float eps, void* stream) {

@@ -557,18 +557,18 @@ def embedding_fwd_ssq(ids, E):
     ids = _need(ids, torch.int64, "ids").reshape(-1)
     V, H = E.shape
     x = torch.empty(ids.numel(), H, dtype=torch.bfloat16, device=E.device)
-    ssq = torch.empty(ids.numel(), H // 128, dtype=torch.float32, device=E.device)
+    ssq = torch.empty(H // 128, ids.numel(), dtype=torch.float32, device=E.device)  # tile-major
     check(load_lib().sd_embedding_fwd_ssq(ids.data_ptr(), _p(E), x.data_ptr(), ssq.data_ptr(), ids.numel(), H, V, _stream()),
           "sd_embedding_fwd_ssq")
     return x, ssq
 
 
 def gemm_resid_ssq(a, w, residual):
-    """C = a . w^T + residual and the per-128-column-tile sums of squares of C: ([M,N] bf16, [M,N/128] fp32)."""
+    """C = a . w^T + residual and the per-128-column-tile sums of squares of C: ([M,N] bf16, [N/128,M] fp32 tile-major)."""
     M, K = a.shape
     N = w.shape[0]
     c = torch.empty(M, N, dtype=torch.bfloat16, device=a.device)
-    ssq = torch.empty(M, N // 128, dtype=torch.float32, device=a.device)
+    ssq = torch.empty(N // 128, M, dtype=torch.float32, device=a.device)
     check(load_lib().sd_gemm_bf16_ssq(_p(a), _p(w), c.data_ptr(), _p(residual), ssq.data_ptr(), M, N, K, a.stride(0),
                                       w.stride(0), N, residual.stride(0), _stream()), "sd_gemm_bf16_ssq")
     return c, ssq

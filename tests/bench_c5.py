@@ -30,6 +30,7 @@ def init(m, seed):
 teacher = sda.HipQwen3ForCausalLM(sda.Qwen3Dims.teacher_17b(), device=dev, init_std=0)
 init(teacher, 1)
 teacher.eval().requires_grad_(False)
+teacher.fold_norm_gains = "--no-fold" not in sys.argv  # A/B: RMSNorm gains folded into the weights (round 4) or launched
 ids = torch.randint(0, 159488, (64, 512), device=dev)
 
 

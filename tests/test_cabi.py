@@ -129,3 +129,27 @@ def test_library_holds_no_undispatched_gemm_kernels():
     blob = open(sda.lib_path(), "rb").read()
     for dead in (b"gemm_p1_kernel", b"gemm_pgroup_nt_kernel", b"gemm_ks_kernel", b"rmsnorm_fwd_slabs_kernel"):
         assert dead not in blob, dead
+
+
+def test_gemm_table_covers_every_baseline_shape_and_is_in_sync():
+    """speech_distill_amd/csrc/sd_gemm_table.inc (compiled into the launcher) holds one entry per GEMM call
+    of the distillation step at the BASELINE config 2 / 4 / 5 shapes -- the same enumeration tests/bench_tune.py measures
+    -- and is exactly what scripts/make_gemm_table.py generates from the committed profile."""
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import importlib
+    calls = importlib.import_module("bench_tune").calls
+    inc = open(os.path.join(ROOT, "speech_distill_amd", "csrc", "sd_gemm_table.inc")).read()
+    have = set()
+    for m in re.finditer(r"^\{(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+)\}", inc, re.M):
+        ta, tb, epi, M, N, K, bm, nst, fl = (int(x) for x in m.groups())
+        assert bm in (0, 64, 128, 256) and (bm == 0) == (nst == 0)
+        have.add((ta, tb, epi, M, N, K))
+    for cfg in ("c2", "c4", "c5"):
+        for name, form, epi, M, N, K in calls(cfg):
+            key = (int(form == "TN"), int(form in ("NN", "TN")), epi, M, N, K)
+            assert key in have, f"{name} {key} has no entry in sd_gemm_table.inc"
+    gen = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "make_gemm_table.py"),
+                          os.path.join("profiles", "r04_gemm_tune.json")], cwd=ROOT, capture_output=True, text=True, check=True)
+    assert gen.stdout == inc, "sd_gemm_table.inc is stale: regenerate it with scripts/make_gemm_table.py"

@@ -149,6 +149,32 @@ def test_gemm_fused_epilogues_equal_the_separate_kernels(ops, bm, nst):
     assert torch.equal(act, act_ref) and torch.equal(act2, act_ref), float((act.float() - act_ref.float()).abs().max())
 
 
+def test_gemm_table_entries_change_the_kernel_not_the_result(ops):
+    """Dispatch by measurement (csrc/sd_gemm_table.inc): for shapes the table overrides -- config 4's gate|up dX (split-K
+    plan, 256x3 instead of the staggered kernel) and student gate|up forward (the 256x256 kernel below its usual tile
+    threshold) -- the table picks ANOTHER kernel than the heuristic ("gemm.no_table" = 1) and the result is the same bits."""
+    g = torch.Generator().manual_seed(44)
+    cases = [((8192, 6144), (6144, 1024), False, True, True),     # dY [M, 2I] . Wgu [2I, h] -> dX [M, h]
+             ((8192, 1024), (6144, 1024), False, False, False)]   # x [M, h] . Wgu [2I, h]^T
+    for ashape, bshape, ta, tb, sk in cases:
+        a = to_dev(bf(torch.randn(*ashape, generator=g)))
+        b = to_dev(bf(torch.randn(*bshape, generator=g) * 0.05))
+        outs, syms = [], []
+        for no_table in (0, 1):
+            _lib.debug_set("gemm.no_table", no_table)
+            _lib.debug_set("gemm.p256_min_tiles", 1024)  # the product default (this module lowers it for other tests)
+            try:
+                ops.prof_begin()
+                outs.append(ops.gemm(a, b, ta, tb, split_k=sk))
+                ops.prof_end()
+                syms.append(sorted(k for k in ops.prof_symbols() if k.startswith("gemm_")))
+            finally:
+                _lib.debug_set("gemm.no_table", 0)
+                _lib.debug_set("gemm.p256_min_tiles", 150)
+        assert syms[0] != syms[1], syms
+        assert torch.equal(outs[0], outs[1]), syms
+
+
 @pytest.mark.parametrize("H", [1024, 2048])
 def test_folded_rmsnorm_pieces(ops, O, H):
     """RMSNorm folded into the projection behind it (include/sd_hip.h; the frozen teacher's inference forward): the
@@ -169,7 +195,7 @@ def test_folded_rmsnorm_pieces(ops, O, H):
     ids = to_dev(torch.randint(0, V, (M,), generator=g))
     x0, ssq0 = ops.embedding_fwd_ssq(ids, E)
     assert torch.equal(x0, ops.embedding_fwd(ids, E))
-    want0 = x0.double().view(M, nt, 128).pow(2).sum(-1)
+    want0 = x0.double().view(M, nt, 128).pow(2).sum(-1).t()  # tile-major [H/128, M]
     np.testing.assert_allclose(ssq0.double().cpu().numpy(), want0.cpu().numpy(), rtol=1e-5)
     a = to_dev(bf(torch.randn(M, Kd, generator=g)))
     w = to_dev(bf(torch.randn(H, Kd, generator=g) * 0.05))
@@ -184,7 +210,7 @@ def test_folded_rmsnorm_pieces(ops, O, H):
     x1, ssq1 = outs[0]
     for c, sq in outs:
         assert torch.equal(c, c_ref) and torch.equal(sq, ssq1)
-    np.testing.assert_allclose(ssq1.double().cpu().numpy(), x1.double().view(M, nt, 128).pow(2).sum(-1).cpu().numpy(), rtol=1e-5)
+    np.testing.assert_allclose(ssq1.double().cpu().numpy(), x1.double().view(M, nt, 128).pow(2).sum(-1).t().cpu().numpy(), rtol=1e-5)
     # ---- consumers: weights with the norm's gain folded in
     gain = bf(1 + 0.3 * torch.randn(H, generator=g))
     wqkv = bf(torch.randn((Hq + 2 * Hkv) * 128, H, generator=g) * 0.05)
