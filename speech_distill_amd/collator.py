@@ -1,16 +1,36 @@
-"""Vectorised counterpart of the reference's ``ProcessedDataCollator`` (data.py:201-387), the
-component that defines the hot path's input contract.
+"""Batch builder with the contract of the reference's ``ProcessedDataCollator`` (data.py:201-387), the component that
+defines the hot path's inputs: same constructor, same output keys, dtypes and values (pinned by
+fixture G3, ``tests/test_collator_golden.py``) --
 
-Same constructor and output keys/dtypes: right-padded ``input_ids`` / ``attention_mask`` (pad =
-``pad_token_id``), ``labels`` = ids with pad -> -100 and every position before the first
-``speech_bos`` -> -100 (a row without ``speech_bos`` is all -100), teacher twins, optional
-pre-extracted ``teacher_top_k_v`` (pad 0.0) / ``teacher_top_k_i`` (pad 0) cut or padded to the
-student length.  Unlike the reference there is no per-row ``.item()`` loop (data.py:374-382): the
-speech mask is one cumulative sum.  Host-side only (runs in dataloader workers).
+* ``input_ids`` / ``attention_mask`` int64, right-padded with ``pad_token_id`` / 0 to the longest row (rounded up to
+  ``pad_to_multiple_of``);
+* ``labels`` = ids where a target exists, else -100: no target at ANY position holding the pad id (quirk Q2: the final
+  ``<|semantic_token_end|>`` equals the pad token, data.py:250-251) nor before the first ``speech_bos`` of a row (a row
+  without one has no targets, data.py:273-276, 350-387);
+* ``teacher_input_ids`` / ``teacher_attention_mask`` when the features carry teacher sequences;
+* ``teacher_top_k_v`` (pad 0.0) / ``teacher_top_k_i`` (pad 0) ``[B, T, K]`` cut or padded to the STUDENT width when the
+  features carry pre-extracted top-K (data.py:330-348).
+
+Built differently from the reference: every ragged field becomes ONE scatter of its concatenated values into a
+pre-filled ``[B, W]`` grid (index vectors from the row lengths: no per-row copy loop, no per-row ``.item()``), and
+``labels`` is one ``where`` over the grid instead of a clone masked twice.  Host-side only (dataloader workers).
 """
-from typing import Any, Dict, List, Optional
+from typing import Any, Dict, List, Optional, Sequence
 
 import torch
+
+
+def _ragged_to_grid(seqs: Sequence, width: int, fill, dtype) -> torch.Tensor:
+    """Right-padded ``[len(seqs), width]`` grid of the ragged ``seqs`` (1-D each), one scatter."""
+    lens = torch.tensor([len(s) for s in seqs], dtype=torch.long)
+    grid = torch.full((len(seqs), width), fill, dtype=dtype)
+    total = int(lens.sum())
+    if total:
+        flat = torch.cat([torch.as_tensor(s, dtype=dtype).reshape(-1) for s in seqs])
+        row = torch.repeat_interleave(torch.arange(len(seqs)), lens)
+        col = torch.arange(total) - torch.repeat_interleave(torch.cumsum(lens, 0) - lens, lens)
+        grid[row, col] = flat
+    return grid
 
 
 class ProcessedDataCollator:
@@ -21,59 +41,50 @@ class ProcessedDataCollator:
         self.pad_to_multiple_of = pad_to_multiple_of
         self.speech_bos = speech_bos
 
-    def _pad_sequences(self, ids_list, mask_list):
-        n = max(len(x) for x in ids_list)
-        if self.pad_to_multiple_of is not None:
-            m = self.pad_to_multiple_of
-            n = (n + m - 1) // m * m
-        ids = torch.full((len(ids_list), n), self.pad_token_id, dtype=torch.long)
-        am = torch.zeros((len(ids_list), n), dtype=torch.long)
-        for r, (a, b) in enumerate(zip(ids_list, mask_list)):
-            ids[r, : len(a)] = torch.as_tensor(a, dtype=torch.long)
-            am[r, : len(b)] = torch.as_tensor(b, dtype=torch.long)
-        return {"input_ids": ids, "attention_mask": am}
+    # ------------------------------------------------------------------------------------------------ pieces
+    def _width(self, seqs) -> int:
+        w = max(len(s) for s in seqs)
+        m = self.pad_to_multiple_of
+        return w if m is None else -(-w // m) * m
 
-    @staticmethod
-    def _pad_logits(lst, max_length, padding_value=0.0):
-        out = []
-        for l in lst:
-            l = l if isinstance(l, torch.Tensor) else torch.as_tensor(l)
-            if l.size(0) < max_length:
-                l = torch.cat([l, torch.full((max_length - l.size(0), l.size(1)), padding_value, dtype=l.dtype)], 0)
-            out.append(l[:max_length])
-        return torch.stack(out)
+    def _ids_and_mask(self, ids_seqs, mask_seqs):
+        w = self._width(ids_seqs)
+        return (_ragged_to_grid(ids_seqs, w, self.pad_token_id, torch.long), _ragged_to_grid(mask_seqs, w, 0, torch.long))
 
-    def _create_speech_token_mask(self, input_ids):
+    def _speech_bos_id(self) -> Optional[int]:
+        """Token id of ``speech_bos``; None (= no text masking, as the reference does on a tokenizer failure) otherwise."""
         try:
             tok = self.tokenizer.encode(self.speech_bos, add_special_tokens=False)
-            if not tok:
-                return None
-            return ((input_ids == tok[0]).cumsum(-1) > 0).to(torch.float32)
         except Exception:
             return None
+        return tok[0] if tok else None
 
+    @staticmethod
+    def _topk_grid(items, width: int, fill) -> torch.Tensor:
+        """Per-sample ``[len_i, K]`` -> ``[B, width, K]``: rows past ``width`` are cut, missing rows take ``fill``."""
+        first = items[0] if isinstance(items[0], torch.Tensor) else torch.as_tensor(items[0])
+        out = torch.full((len(items), width, first.size(1)), fill, dtype=first.dtype)
+        for b, it in enumerate(items):
+            it = it if isinstance(it, torch.Tensor) else torch.as_tensor(it)
+            n = min(width, it.size(0))
+            out[b, :n] = it[:n]
+        return out
+
+    # -------------------------------------------------------------------------------------------------- call
     def __call__(self, features: List[Dict[str, Any]]) -> Dict[str, torch.Tensor]:
-        s_ids = [f["student_input_ids"] for f in features if "student_input_ids" in f]
-        s_am = [f["student_attention_mask"] for f in features if "student_attention_mask" in f]
-        t_ids = [f.get("teacher_input_ids") for f in features if "teacher_input_ids" in f]
-        t_am = [f.get("teacher_attention_mask") for f in features if "teacher_attention_mask" in f]
-        if not s_ids:
-            s_ids = [f["input_ids"] for f in features]
-            s_am = [f["attention_mask"] for f in features]
-        batch = self._pad_sequences(s_ids, s_am)
-        batch["labels"] = batch["input_ids"].clone()
-        if self.pad_token_id is not None:
-            batch["labels"][batch["labels"] == self.pad_token_id] = -100
-        if t_ids and t_ids[0] is not None:
-            tb = self._pad_sequences(t_ids, t_am)
-            batch["teacher_input_ids"], batch["teacher_attention_mask"] = tb["input_ids"], tb["attention_mask"]
-        top_v = [f.get("teacher_top_k_v") for f in features if "teacher_top_k_v" in f]
-        top_i = [f.get("teacher_top_k_i") for f in features if "teacher_top_k_i" in f]
-        if top_v and top_v[0] is not None:
-            n = batch["input_ids"].size(1)
-            batch["teacher_top_k_v"] = self._pad_logits(top_v, n, 0.0)
-            batch["teacher_top_k_i"] = self._pad_logits(top_i, n, 0)
-        sm = self._create_speech_token_mask(batch["input_ids"])
-        if sm is not None:
-            batch["labels"][sm == 0] = -100
+        paired = "student_input_ids" in features[0]
+        ids_key, am_key = ("student_input_ids", "student_attention_mask") if paired else ("input_ids", "attention_mask")
+        ids, am = self._ids_and_mask([f[ids_key] for f in features], [f[am_key] for f in features])
+        # one predicate for "this position has a target": not the pad id, and at / after the row's first speech_bos
+        has_target = torch.ones_like(ids, dtype=torch.bool) if self.pad_token_id is None else ids != self.pad_token_id
+        bos = self._speech_bos_id()
+        if bos is not None:
+            has_target &= (ids == bos).cumsum(-1) > 0
+        batch = {"input_ids": ids, "attention_mask": am, "labels": torch.where(has_target, ids, torch.full_like(ids, -100))}
+        if features[0].get("teacher_input_ids") is not None:
+            batch["teacher_input_ids"], batch["teacher_attention_mask"] = self._ids_and_mask(
+                [f["teacher_input_ids"] for f in features], [f["teacher_attention_mask"] for f in features])
+        if features[0].get("teacher_top_k_v") is not None:
+            batch["teacher_top_k_v"] = self._topk_grid([f["teacher_top_k_v"] for f in features], ids.size(1), 0.0)
+            batch["teacher_top_k_i"] = self._topk_grid([f["teacher_top_k_i"] for f in features], ids.size(1), 0)
         return batch
