@@ -229,6 +229,37 @@ int sd_adamw_bf16(void* param, const void* grad, void* exp_avg, void* exp_avg_sq
                   float beta2, float eps, float weight_decay, int step, const float* grad_sumsq, float max_grad_norm,
                   void* stream);
 
+/* ---- LoRA student (train.py:180-202: peft LoRA, r = 32, on q/k/v/o/gate/up/down_proj of every decoder layer;
+ * parity unpinned -- peft is an unvendored dependency, oracle/lora.py restates its published layer).
+ * The adapter is applied to the MERGED weight: W_eff = W_res + (s B) A once per optimizer step (sd_lora_merge), the
+ * decoder backward writes the full weight gradient dW, and dA = (s B)^T dW, dB = dW (s A)^T (sd_lora_project).  All
+ * targets go in ONE launch each, driven by a plan the host builds once.
+ *   A [r_pad, in] and B [out, r_pad] are fp32 masters (rows / columns r..r_pad are zero and stay zero; r_pad = r
+ *   rounded up to 32, 64 or 128); the kernels read their bf16 shadows, written by sd_adamw_f32_shadow:
+ *   a_shadow = bf16(A), a_scaled = bf16(s A), b_scaled = bf16(s B).  d_a / d_b: bf16, same shapes as A / B.
+ * Shapes: in_features % 128 == 0, out_features % 32 == 0, else SD_ERR_UNSUPPORTED; every pointer 16-byte aligned. */
+typedef struct {
+  const void* w_res;   /* [out, in] bf16: frozen (residual) base weight */
+  void* w_out;         /* [out, in] bf16: merged weight the decoder reads */
+  const void* w_grad;  /* [out, in] bf16: gradient w.r.t. the merged weight */
+  const void* a_shadow;
+  const void* a_scaled;
+  const void* b_scaled;
+  void* d_a;
+  void* d_b;
+  int32_t out_features, in_features;
+} SdLoraTarget;
+int64_t sd_lora_plan_bytes(int n_targets);
+/* Fills `plan_host` (host memory, sd_lora_plan_bytes(n) bytes); the caller copies it to the device once. */
+int sd_lora_plan_build(const SdLoraTarget* targets, int n_targets, int r_pad, void* plan_host, int64_t plan_bytes);
+int sd_lora_merge(const void* plan_dev, const void* plan_host, void* stream);
+int sd_lora_project(const void* plan_dev, const void* plan_host, void* stream);
+/* AdamW on fp32 parameters with fp32 moments and a bf16 gradient (same update rule and clip as sd_adamw_bf16), also
+ * writing shadow = bf16(p) and shadow_scaled = bf16(scale * p).  n % 4 == 0. */
+int sd_adamw_f32_shadow(float* param, const void* grad, float* exp_avg, float* exp_avg_sq, void* shadow,
+                        void* shadow_scaled, float scale, int64_t n, float lr, float beta1, float beta2, float eps,
+                        float weight_decay, int step, const float* grad_sumsq, float max_grad_norm, void* stream);
+
 /* ---- whole-decoder runner: Qwen3ForCausalLM forward (HF:381-441) / backward, one C call each.
  * Weight layout: q|k|v projections fused row-wise into wqkv [(Hq+2Hkv)*128, h]; gate|up into wgu [2I, h]. */
 typedef struct {

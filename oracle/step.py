@@ -69,7 +69,7 @@ def collate(features, pad_token_id, speech_bos_id, pad_to_multiple_of=None):
 
 
 def distill_step(student_w, student_shape, teacher_w, teacher_shape, batch, temperature=2.0, alpha=0.5,
-                 top_k=100, is_quantized_teacher=False, with_grad=True, acc=torch.float64, storage=None):
+                 top_k=100, is_quantized_teacher=False, with_grad=True, acc=torch.float64, storage=None, grad_wrt=None):
     """One compute_loss (+ backward).  Returns dict(total, task, distill, teacher, grads, logits).
 
     storage="bf16": the error-budget mode of oracle/qwen3.py -- weights rounded to bf16 (the HIP model keeps bf16
@@ -81,7 +81,11 @@ def distill_step(student_w, student_shape, teacher_w, teacher_shape, batch, temp
         student_w = {k: v.to(torch.bfloat16).to(v.dtype) for k, v in student_w.items()}
         if teacher_w is not None:
             teacher_w = {k: v.to(torch.bfloat16).to(v.dtype) for k, v in teacher_w.items()}
-    sw = {k: v.detach().clone().requires_grad_(with_grad) for k, v in student_w.items()}
+    if grad_wrt is None:
+        sw = {k: v.detach().clone().requires_grad_(with_grad) for k, v in student_w.items()}
+        wrt = sw
+    else:   # student_w is built (differentiably) from the leaves in grad_wrt: oracle/lora.py
+        sw, wrt = student_w, grad_wrt
     logits = Q.forward(sw, student_shape, batch["input_ids"], batch.get("attention_mask"), storage=storage)
     tkv, tki = batch.get("teacher_top_k_v"), batch.get("teacher_top_k_i")
     t_logits = None
@@ -104,7 +108,7 @@ def distill_step(student_w, student_shape, teacher_w, teacher_shape, batch, temp
     if with_grad and total.requires_grad:
         total.backward()
         out["grads"] = {k: (v.grad.to(torch.bfloat16).to(v.grad.dtype) if storage == "bf16" else v.grad)
-                        for k, v in sw.items()}
+                        for k, v in wrt.items() if v.grad is not None}
     return out
 
 

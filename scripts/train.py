@@ -60,7 +60,7 @@ def parse_args():
     # teacher always stays bf16 in HBM (3.5 GB of 288); the flags keep their effect on the loss
     p.add_argument("--load_teacher_in_4bit", action="store_true")
     p.add_argument("--load_teacher_in_8bit", action="store_true")
-    # LoRA (train.py:180-202) is a documented user flow outside the hot path: refused loudly
+    # LoRA (train.py:180-202, :470-487): speech_distill_amd/lora.py, merged-weight form
     p.add_argument("--use_lora", action="store_true")
     p.add_argument("--lora_r", type=int, default=32)
     p.add_argument("--lora_alpha", type=int, default=64)
@@ -117,11 +117,16 @@ def main():
     torch.cuda.set_device(dev)
     student, teacher = build_models(cfg, dev)
     teacher.eval().requires_grad_(False)               # train.py:165-169
+    if cfg.use_lora:                                   # train.py:180-203
+        from speech_distill_amd import lora
+        print("Applying LoRA to student model...")
+        init = cfg.init_lora_weights
+        init = True if init in ("default", "true", "True") else init
+        student = lora.get_lora_model(student, lora.LoraConfig(
+            r=cfg.lora_r, lora_alpha=cfg.lora_alpha, use_rslora=cfg.use_rslora, init_lora_weights=init))
+        lora.print_trainable_parameters(student)
     # train.py:204-208; layer-granular recompute only when the policy asks for it ("auto": when HBM would run short)
     student.gradient_checkpointing_enable(gradient_checkpointing_kwargs={"recompute": cfg.recompute})
-    if cfg.use_lora:
-        raise NotImplementedError("--use_lora (train.py:180-202, PEFT LoRA on the student) is outside the MI355X hot path: "
-                                  "the flat-buffer student trains all parameters")
     V = student.dims.vocab_size
     bos = cfg.speech_bos_id if cfg.speech_bos_id is not None else (152927 if V > 152928 else V // 2)
     pad = cfg.pad_token_id if cfg.pad_token_id < V else V - 1

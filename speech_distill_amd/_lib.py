@@ -50,6 +50,11 @@ class Layer(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("wqkv", "wo", "wgu", "wdown", "q_gain", "k_gain", "ln1", "ln2")]
 
 
+class LoraTarget(C.Structure):   # include/sd_hip.h SdLoraTarget
+    _fields_ = [(n, C.c_void_p) for n in ("w_res", "w_out", "w_grad", "a_shadow", "a_scaled", "b_scaled", "d_a", "d_b")] + \
+               [("out_features", C.c_int32), ("in_features", C.c_int32)]
+
+
 class Params(C.Structure):
     _fields_ = [("embed", C.c_void_p), ("lm_head", C.c_void_p), ("final_norm", C.c_void_p),
                 ("layers_host", C.POINTER(Layer))]
@@ -117,6 +122,11 @@ PROTOTYPES = {
     "sd_colsum_reduce_batch": (_i, [_vp, _i, _vp]),
     "sd_sumsq_bf16": (_i, [_vp, _i64, _vp, _vp, _vp]),
     "sd_adamw_bf16": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _vp, _f, _vp]),
+    "sd_lora_plan_bytes": (_i64, [_i]),
+    "sd_lora_plan_build": (_i, [C.POINTER(LoraTarget), _i, _i, _vp, _i64]),
+    "sd_lora_merge": (_i, [_vp, _vp, _vp]),
+    "sd_lora_project": (_i, [_vp, _vp, _vp]),
+    "sd_adamw_f32_shadow": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _i64, _f, _f, _f, _f, _f, _i, _vp, _f, _vp]),
     "sd_streams_overlap": (_i, [_vp, _vp, _f, C.POINTER(C.c_int)]),
     "sd_prof_begin": (_i, []),
     "sd_prof_end": (_i, [_vp, _vp, _vp, _i]),

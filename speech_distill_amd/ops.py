@@ -478,6 +478,14 @@ def adamw_(p, g, m, v, lr, beta1, beta2, eps, wd, step, grad_sumsq=None, max_nor
                                    eps, wd, step, _p(grad_sumsq), max_norm, _stream()), "sd_adamw_bf16")
 
 
+def adamw_f32_shadow_(p, g, m, v, shadow, shadow_scaled, scale, lr, beta1, beta2, eps, wd, step, grad_sumsq=None,
+                       max_norm=0.0):
+    """AdamW on fp32 masters with a bf16 gradient; also writes shadow = bf16(p), shadow_scaled = bf16(scale p)."""
+    check(load_lib().sd_adamw_f32_shadow(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), shadow.data_ptr(),
+                                         shadow_scaled.data_ptr(), scale, p.numel(), lr, beta1, beta2, eps, wd, step,
+                                         _p(grad_sumsq), max_norm, _stream()), "sd_adamw_f32_shadow")
+
+
 # --------------------------------------------------------------------------------------- profiling
 def prof_begin():
     check(load_lib().sd_prof_begin(), "sd_prof_begin")

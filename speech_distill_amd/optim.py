@@ -22,23 +22,27 @@ class FlatAdamW(torch.optim.Optimizer):
         self.model = model
         params = [p for p in model.parameters() if p.requires_grad]
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, clip=clip))
-        self.exp_avg = torch.zeros_like(model.flat)
-        self.exp_avg_sq = torch.zeros_like(model.flat)
-        self._sumsq = torch.zeros(1, dtype=torch.float32, device=model.flat.device)
-        self._partials = torch.empty(_lib.SUMSQ_PARTIALS, dtype=torch.float32, device=model.flat.device)  # sd_sumsq_bf16 scratch, this optimizer's own
+        # Moments: one flat buffer per kind, laid out in the order of model.optim_segments() -- for the fully trained
+        # student that is the model's own flat layout; a LoRA student (lora.py) has its two saved modules in bf16 and
+        # the adapter's fp32 masters.
+        dev = model.flat.device
+        segs = model.optim_segments()
+        n16 = sum(p.numel() for kind, p, *_ in segs if kind == "bf16")
+        n32 = sum(p.numel() for kind, p, *_ in segs if kind == "f32_shadow")
+        self.exp_avg = torch.zeros(n16, dtype=torch.bfloat16, device=dev)
+        self.exp_avg_sq = torch.zeros(n16, dtype=torch.bfloat16, device=dev)
+        self.exp_avg32 = torch.zeros(n32, dtype=torch.float32, device=dev) if n32 else None
+        self.exp_avg_sq32 = torch.zeros(n32, dtype=torch.float32, device=dev) if n32 else None
+        self._sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._partials = torch.empty(_lib.SUMSQ_PARTIALS, dtype=torch.float32, device=dev)  # sd_sumsq_bf16 scratch, this optimizer's own
         self._step = 0
         self._measured_clip = None  # set by grad_norm() for the following step()
-        # contiguous runs of matrices / gains in the flat layout (for decay on matrices only)
-        runs, cur = [], None
-        for name, (o, n, shape) in model._slices.items():
-            is_mat = len(shape) == 2
-            n8 = (n + 7) // 8 * 8
-            if cur is not None and cur[2] == is_mat and cur[1] == o:
-                cur[1] = o + n8
-            else:
-                cur = [o, o + n8, is_mat]
-                runs.append(cur)
-        self._runs = [(a, b, m) for a, b, m in runs]
+
+    def _reduce_sumsq(self):
+        self.model.finalize_grads()     # (a LoRA student projects dW onto its adapter here)
+        self._sumsq.zero_()
+        for _, _, g, _, _ in self.model.optim_segments():
+            ops.sumsq(g, self._sumsq, self._partials)
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -52,15 +56,26 @@ class FlatAdamW(torch.optim.Optimizer):
         if self._measured_clip is not None:   # grad_norm() already reduced THIS gradient: the kernel clips against it
             clip, ss, self._measured_clip = self._measured_clip, self._sumsq, None
         elif clip > 0:
-            self._sumsq.zero_()
-            ops.sumsq(m.flat_grad, self._sumsq, self._partials)
+            self._reduce_sumsq()
             ss = self._sumsq
+        else:
+            m.finalize_grads()
         b1, b2 = g["betas"]
         wd = float(g["weight_decay"])
-        spans = [(0, m.numel_flat, True)] if wd == 0.0 else self._runs
-        for a, b, is_mat in spans:
-            ops.adamw_(m.flat[a:b], m.flat_grad[a:b], self.exp_avg[a:b], self.exp_avg_sq[a:b], float(g["lr"]), b1, b2,
-                       g["eps"], wd if is_mat else 0.0, self._step, ss, clip)
+        o16 = o32 = 0
+        for kind, p, gr, is_mat, extra in m.optim_segments(split_decay=wd != 0.0):
+            n = p.numel()
+            if kind == "bf16":
+                ops.adamw_(p, gr, self.exp_avg[o16:o16 + n], self.exp_avg_sq[o16:o16 + n], float(g["lr"]), b1, b2, g["eps"],
+                           wd if is_mat else 0.0, self._step, ss, clip)
+                o16 += n
+            else:
+                shadow, shadow_scaled, scale, owner = extra
+                ops.adamw_f32_shadow_(p, gr, self.exp_avg32[o32:o32 + n], self.exp_avg_sq32[o32:o32 + n], shadow,
+                                      shadow_scaled, scale, float(g["lr"]), b1, b2, g["eps"], wd if is_mat else 0.0,
+                                      self._step, ss, clip)
+                owner.mark_updated()
+                o32 += n
         return None
 
     @torch.no_grad()
@@ -69,15 +84,16 @@ class FlatAdamW(torch.optim.Optimizer):
         trainer.py:2535-2539); the next ``step()`` applies min(1, max_norm / (norm + 1e-6)) to the gradient INSIDE the
         fused update instead of rewriting the 1.2 GB gradient buffer first (``.grad`` itself stays unclipped).
         max_norm = inf (HF asks that way for the norm alone) or <= 0: measure only."""
-        self._sumsq.zero_()
-        ops.sumsq(self.model.flat_grad, self._sumsq, self._partials)
+        self._reduce_sumsq()
         self._measured_clip = float(max_norm) if 0 < max_norm < float("inf") else 0.0
         return self._sumsq.sqrt().squeeze(0)
 
     def state_dict(self):
-        """HF Trainer checkpoints ``optimizer.state_dict()`` (optimizer.pt): the flat bf16 moments + step count."""
+        """HF Trainer checkpoints ``optimizer.state_dict()`` (optimizer.pt): the flat moments + step count."""
         sd = super().state_dict()
         sd["flat"] = {"exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "step": self._step}
+        if self.exp_avg32 is not None:
+            sd["flat"].update(exp_avg32=self.exp_avg32, exp_avg_sq32=self.exp_avg_sq32)
         return sd
 
     def load_state_dict(self, state_dict):
@@ -87,6 +103,9 @@ class FlatAdamW(torch.optim.Optimizer):
         if flat is not None:
             self.exp_avg.copy_(flat["exp_avg"])
             self.exp_avg_sq.copy_(flat["exp_avg_sq"])
+            if self.exp_avg32 is not None:
+                self.exp_avg32.copy_(flat["exp_avg32"])
+                self.exp_avg_sq32.copy_(flat["exp_avg_sq32"])
             self._step = int(flat["step"])
 
     def last_grad_norm(self):

@@ -208,6 +208,7 @@ class HipQwen3ForCausalLM(nn.Module):
         # the folded copies are rebuilt whenever the flat parameter buffer has been written to (version counter).
         self.fold_norm_gains = True
         self._folded = None  # (flat._version, folded weight buffer, Params, Layers)
+        self._lora = None    # lora.LoraState once lora.get_lora_model() has attached an adapter (train.py:180-202)
         if init_std:
             self.init_weights(seed, init_std)
 
@@ -232,6 +233,8 @@ class HipQwen3ForCausalLM(nn.Module):
         self._anchor = torch.zeros((), device=new_flat.device, requires_grad=True)
         self._cparams, self._clayers = self._c_struct(self.flat)
         self._rope, self._side_stream = {}, None
+        if self._lora is not None:
+            self._lora.rebind(fn)
         return self
 
     @staticmethod
@@ -305,6 +308,8 @@ class HipQwen3ForCausalLM(nn.Module):
     def state_dict(self, *args, destination=None, prefix="", keep_vars=False):
         """HF key names -> tensors (views of the flat buffer).  A tied ``lm_head.weight`` is left out, as in an HF
         checkpoint: it is the same memory as ``model.embed_tokens.weight`` and safetensors refuses aliases."""
+        if self._lora is not None:   # a LoRA student checkpoints its adapter (peft's adapter state dict), lora.py
+            return self._lora.state_dict(prefix)
         sd = super().state_dict(*args, destination=destination, prefix=prefix, keep_vars=keep_vars)
         tied = self._tied_head_key(prefix)
         if tied is not None:
@@ -316,6 +321,8 @@ class HipQwen3ForCausalLM(nn.Module):
         ``_IncompatibleKeys``; a tied ``lm_head.weight`` is neither required nor, when present, unexpected
         (it must then equal the embedding, which is what gets loaded)."""
         from torch.nn.modules.module import _IncompatibleKeys
+        if self._lora is not None:
+            return self._lora.load_state_dict(state_dict, strict)
         tied = self._tied_head_key()
         want = [k for k in self._params if k != tied] if tied else list(self._params)
         if tied and "lm_head.weight" in self._params:
@@ -338,6 +345,8 @@ class HipQwen3ForCausalLM(nn.Module):
     def save_pretrained(self, save_directory, state_dict=None, safe_serialization=True, **kwargs):
         """HF-loadable checkpoint directory: ``config.json`` (+ ``model.safetensors`` / ``pytorch_model.bin``).
         ``AutoModelForCausalLM.from_pretrained(dir)`` and ``HipQwen3ForCausalLM.from_pretrained(dir)`` both read it."""
+        if self._lora is not None:   # adapter_config.json + adapter_model.safetensors, as PeftModel.save_pretrained
+            return self._lora.save_pretrained(save_directory, state_dict, safe_serialization)
         os.makedirs(save_directory, exist_ok=True)
         sd = self.state_dict() if state_dict is None else dict(state_dict)
         tied = self._tied_head_key()
@@ -441,7 +450,7 @@ class HipQwen3ForCausalLM(nn.Module):
     def _folded_params(self):
         """C parameter struct whose wqkv / wgu point at W diag(g) (g = the RMSNorm gain in front of the projection,
         HF:59-64, 252-254, 81-83), or None when this model must not or cannot fold."""
-        if not self.fold_norm_gains or any(p.requires_grad for p in self._params.values()):
+        if not self.fold_norm_gains or self._lora is not None or any(p.requires_grad for p in self._params.values()):
             return None
         if not load_lib().sd_qwen3_fold_supported(C.byref(self._cdims)):
             return None
@@ -474,6 +483,8 @@ class HipQwen3ForCausalLM(nn.Module):
         dev = input_ids.device
         cos, sin = self._tables(T, dev)
         cparams = self._cparams
+        if self._lora is not None:
+            self._lora.ensure_merged()   # W_eff = W_res + s B A, rebuilt only after A / B have changed
         if save == SAVE_NONE:
             folded = self._folded_params()
             if folded is not None:
@@ -495,11 +506,13 @@ class HipQwen3ForCausalLM(nn.Module):
         if self.flat_grad is None:
             self.flat_grad = torch.zeros_like(self.flat)
             self._cgrads, self._cglayers = self._c_struct(self.flat_grad)
-        first = next(iter(self._params.values()))
-        accumulate = first.grad is not None and self._grads_live
+        first = next((p for p in self._params.values() if p.requires_grad), None)
+        # (optimizer.zero_grad(set_to_none=True) clears .grad without going through zero_grad() below)
+        accumulate = self._grads_live and (first is None or first.grad is not None)
         if not accumulate:
             for name, (o, n, shape) in self._slices.items():
-                self._params[name].grad = self.flat_grad[o:o + n].view(shape)
+                if self._params[name].requires_grad:  # (a LoRA student's frozen base: the buffer still receives dW)
+                    self._params[name].grad = self.flat_grad[o:o + n].view(shape)
             self._grads_live = True
         return accumulate
 
@@ -515,7 +528,8 @@ class HipQwen3ForCausalLM(nn.Module):
                 # tied embedding/lm_head gradient: the dense lm_head part is all-reduced at the START of
                 # backward; only the B*T rows touched by the embedding lookup are exchanged at the end
                 dx0 = torch.empty(B * T, self.dims.hidden_size, dtype=torch.bfloat16, device=input_ids.device)
-                red.set_embedding_exchange(input_ids.reshape(-1), dx0, self._params["model.embed_tokens.weight"].grad)
+                eo, en, eshape = self._slices["model.embed_tokens.weight"]
+                red.set_embedding_exchange(input_ids.reshape(-1), dx0, self.flat_grad[eo:eo + en].view(eshape))
         if not dlogits.is_contiguous():
             dlogits = dlogits.contiguous()
         cos, sin = self._tables(T, input_ids.device)
@@ -533,6 +547,38 @@ class HipQwen3ForCausalLM(nn.Module):
               "sd_qwen3_backward_rows")
         if red is not None:
             red.finish()
+        if self._lora is not None:
+            self._lora.grads_stale = True
+
+    def finalize_grads(self):
+        """Called by the optimizer / the clipping hook before they read gradients: a LoRA student projects the
+        accumulated weight gradient onto its adapter (dA = s B^T dW, dB = s dW A^T) here, once per optimizer step."""
+        if self._lora is not None:
+            self._lora.project_grads()
+
+    def optim_segments(self, split_decay=False):
+        """What the fused optimizer updates: a list of (kind, params, grads, decays, extra) over flat buffers, in a
+        fixed order.  kind "bf16": bf16 parameters / moments (sd_adamw_bf16); "f32_shadow": fp32 masters with bf16
+        gradients and shadows (sd_adamw_f32_shadow; extra = (shadow, shadow_scaled, scale))."""
+        g = self.flat_grad
+        if self._lora is not None:
+            return self._lora.optim_segments()
+        if not split_decay:
+            return [("bf16", self.flat, g, True, None)]
+        return [("bf16", self.flat[a:b], None if g is None else g[a:b], m, None) for a, b, m in self._decay_runs()]
+
+    def _decay_runs(self):
+        """Contiguous runs of matrices / gains in the flat layout (weight decay applies to matrices only)."""
+        runs, cur = [], None
+        for name, (o, n, shape) in self._slices.items():
+            is_mat = len(shape) == 2
+            n8 = (n + 7) // 8 * 8
+            if cur is not None and cur[2] == is_mat and cur[1] == o:
+                cur[1] = o + n8
+            else:
+                cur = [o, o + n8, is_mat]
+                runs.append(cur)
+        return [(a, b, m) for a, b, m in runs]
 
     def _side_stream_ptr(self, device):
         """Second HIP stream for the weight-gradient GEMMs (they overlap the dX chain); None disables it."""
@@ -563,7 +609,7 @@ class HipQwen3ForCausalLM(nn.Module):
                 raise ValueError("attention_mask is not right-padded (a 1 follows a 0): the HIP attention kernels take a "
                                  "valid-prefix length per sequence, as ProcessedDataCollator produces (data.py:280-327)")
             kv_len = am.sum(-1).to(torch.int32).contiguous()
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self._params.values()):
+        if torch.is_grad_enabled() and (self._lora is not None or any(p.requires_grad for p in self._params.values())):
             logits = _DecoderFn.apply(self._anchor, ids, kv_len, self, rows)
         else:
             logits, _ = self._run_forward(ids, kv_len, save=SAVE_NONE, rows=rows)

@@ -87,11 +87,15 @@ class DistillationTrainer(Trainer):
         core = ddp.unwrap(self.model)
         default_adamw = str(getattr(self.args.optim, "value", self.args.optim)).startswith("adamw_torch")
         if (self.optimizer is None and self.fused_optimizer and default_adamw and isinstance(core, HipQwen3ForCausalLM)
-                and core.flat.is_cuda and all(p.requires_grad for p in core.parameters())):
+                and core.flat.is_cuda and (core._lora is not None or all(p.requires_grad for p in core.parameters()))):
             from .optim import FlatAdamW
             self.optimizer = FlatAdamW(core, lr=self.args.learning_rate, betas=(self.args.adam_beta1, self.args.adam_beta2),
                                        eps=self.args.adam_epsilon, weight_decay=self.args.weight_decay)
             return self.optimizer
+        if isinstance(core, HipQwen3ForCausalLM) and core._lora is not None and self.optimizer is None:
+            raise NotImplementedError("a LoRA student (lora.py) trains through FlatAdamW only: its adapter gradients are "
+                                      "bf16 projections of the flat weight gradient next to fp32 masters; leave "
+                                      "TrainingArguments.optim at its adamw_torch default, as the reference does")
         # (HF calls create_optimizer(model) on its delay_optimizer_creation path: FSDP / SageMaker model parallel)
         return super().create_optimizer(model) if model is not None else super().create_optimizer()
 
@@ -105,6 +109,7 @@ class DistillationTrainer(Trainer):
             from .optim import FlatAdamW
             if isinstance(opt, FlatAdamW) and opt.model is core:
                 return opt.grad_norm(self.args.max_grad_norm)
+            core.finalize_grads()
             ss = torch.zeros(1, dtype=torch.float32, device=core.flat_grad.device)
             ops.sumsq(core.flat_grad, ss)
             norm = ss.sqrt().squeeze(0)
@@ -125,6 +130,15 @@ class DistillationTrainer(Trainer):
         if self.processing_class is not None and hasattr(self.processing_class, "save_pretrained"):
             self.processing_class.save_pretrained(output_dir)
         torch.save(self.args, os.path.join(output_dir, "training_args.bin"))
+
+    def _load_best_model(self):
+        """HF's loader looks for ``model.safetensors``; a LoRA student's checkpoints hold the adapter (``_save`` above)."""
+        core = ddp.unwrap(self.model)
+        best = self.state.best_model_checkpoint
+        if isinstance(core, HipQwen3ForCausalLM) and core._lora is not None and best is not None:
+            core._lora.load_adapter(best)
+            return
+        return super()._load_best_model()
 
     def _teacher_pass(self, inputs, teacher_input_ids, teacher_attention_mask, vocab_size, rows=None, model_kw=None):
         """train.py:60-94: teacher no-grad forward, then on-the-fly top-K unless quantized / top_k <= 0.
