@@ -199,7 +199,9 @@ def main():
                        "world_size": int(os.environ.get("WORLD_SIZE", 1)), "wrapped": type(trainer.model_wrapped).__name__,
                        "optimizer": type(getattr(trainer.optimizer, "optimizer", trainer.optimizer)).__name__,
                        "reducer": None if red is None else red.stats, "global_step": trainer.state.global_step,
-                       "param_checksum": float(student.flat.double().sum())}, f)
+                       "param_checksum": float(student.flat.double().sum()),
+                       "adapter_checksum": None if student._lora is None else float(student._lora.master.double().abs().sum()),
+                       "trainable": sorted({n.split(".")[-2] for n, q in student.named_parameters() if q.requires_grad})}, f)
 
 
 if __name__ == "__main__":

@@ -33,7 +33,7 @@ static_assert(sizeof(PlanHeader) == 32 && sizeof(PlanEntry) == 96, "plan layout"
 
 constexpr int kMergeRows = 256;  // rows one merge item walks (16 MFMA row tiles) with its A operand held in registers
 constexpr int kColBlock = 128;   // columns per merge / dA item
-constexpr int kDbRows = 32;      // rows per dB item (one wave)
+constexpr int kDbRows = 64;      // rows per dB item (one workgroup)
 
 template <int WHICH> SD_DEV int plan_find(const PlanEntry* e, int n, int item) {
   int lo = 0, hi = n - 1;  // last entry whose base <= item
@@ -96,47 +96,55 @@ __global__ __launch_bounds__(256) void lora_merge_kernel(const PlanHeader* __res
 }
 
 // ------------------------------------------------------------------------------------------------------------------- dB
-// dB[out, r_pad] = dW[out, in] (sA)^T: both operands are K-contiguous.  One wave per 32 rows, all of K.  A 64-deep
-// k-step is split so that lane group g owns k in [16 g, 16 g + 16): one 32-byte load per operand row feeds two MFMAs
-// (the labelling of k is free as long as both operands agree), and a dW row is read in whole 128-byte lines.
+// dB[out, r_pad] = dW[out, in] (sA)^T: both operands are K-contiguous, so the MFMA operands are plain 16-byte global
+// loads.  One WORKGROUP per 64 rows (four row tiles share every (sA) operand: it comes from L2 once per 64 rows);
+// its four waves take interleaved 128-column slices of K, so that together they read 1 KB of every row at a time, and
+// their partial sums are added through LDS in a fixed order (no atomics).
+constexpr int kDbTiles = kDbRows / 16;
 template <int NB>
 __global__ __launch_bounds__(256) void lora_db_kernel(const PlanHeader* __restrict__ plan) {
+  __shared__ float part[4][kDbTiles * NB * 4][64];
   const PlanEntry* ents = (const PlanEntry*)(plan + 1);
-  const int item = blockIdx.x * 4 + wave_id_uniform();
-  if (item >= plan->db_items) return;
+  const int item = blockIdx.x;
   const PlanEntry& E = ents[plan_find<1>(ents, plan->n, item)];
   const int row0 = (item - E.db_base) * kDbRows;
   const int in_f = E.in_f, r_pad = NB * 16;
-  const int l = lane_id(), lr = l & 15, lg = l >> 4;
-  const bool two = row0 + 16 < E.out_f;  // wave-uniform: out_f is a multiple of 16
-  const bf16* g0 = E.w_grad + (long)(row0 + lr) * in_f + lg * 16;
-  const bf16* g1 = g0 + (two ? 16L * in_f : 0);
-  const bf16* ap = E.a_scaled + (long)lr * in_f + lg * 16;
-  f32x4 acc[2][NB];
+  const int l = lane_id(), lr = l & 15, lg = l >> 4, wv = wave_id_uniform();
+  const int tiles = min(kDbTiles, (E.out_f - row0) / 16);   // out_f % 32 == 0: a short last block has 2 tiles
+  const bf16* gx[kDbTiles];
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
+  for (int t = 0; t < kDbTiles; ++t) gx[t] = E.w_grad + (long)(row0 + (t < tiles ? t * 16 : 0) + lr) * in_f + lg * 8;
+  const bf16* ap = E.a_scaled + (long)lr * in_f + lg * 8;
+  f32x4 acc[kDbTiles][NB];
+#pragma unroll
+  for (int t = 0; t < kDbTiles; ++t)
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) acc[t][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int k0 = 0; k0 < in_f; k0 += 64) {
-    const bf16x8 x0a = *(const bf16x8*)(g0 + k0), x0b = *(const bf16x8*)(g0 + k0 + 8);
-    const bf16x8 x1a = *(const bf16x8*)(g1 + k0), x1b = *(const bf16x8*)(g1 + k0 + 8);
+  for (int kb = wv * 128; kb < in_f; kb += 512) {   // in_f % 128 == 0
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-      const bf16x8 ya = *(const bf16x8*)(ap + (long)nb * 16 * in_f + k0), yb = *(const bf16x8*)(ap + (long)nb * 16 * in_f + k0 + 8);
-      acc[0][nb] = mfma16(x0a, ya, acc[0][nb]);
-      acc[0][nb] = mfma16(x0b, yb, acc[0][nb]);
-      acc[1][nb] = mfma16(x1a, ya, acc[1][nb]);
-      acc[1][nb] = mfma16(x1b, yb, acc[1][nb]);
+    for (int h = 0; h < 4; ++h) {
+      bf16x8 x[kDbTiles], y[NB];
+#pragma unroll
+      for (int t = 0; t < kDbTiles; ++t) x[t] = *(const bf16x8*)(gx[t] + kb + h * 32);
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) y[nb] = *(const bf16x8*)(ap + (long)nb * 16 * in_f + kb + h * 32);
+#pragma unroll
+      for (int t = 0; t < kDbTiles; ++t)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[t][nb] = mfma16(x[t], y[nb], acc[t][nb]);
     }
   }
 #pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    if (t == 1 && !two) break;
+  for (int t = 0; t < kDbTiles; ++t)
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        E.d_b[(long)(row0 + t * 16 + lg * 4 + i) * r_pad + nb * 16 + lr] = (bf16)acc[t][nb][i];
+      for (int i = 0; i < 4; ++i) part[wv][(t * NB + nb) * 4 + i][l] = acc[t][nb][i];
+  __syncthreads();
+  for (int c = wv; c < tiles * NB * 4; c += 4) {
+    const float v = ((part[0][c][l] + part[1][c][l]) + part[2][c][l]) + part[3][c][l];
+    const int i = c & 3, nb = (c >> 2) % NB, t = (c >> 2) / NB;
+    E.d_b[(long)(row0 + t * 16 + lg * 4 + i) * r_pad + nb * 16 + lr] = (bf16)v;
   }
 }
 
@@ -323,7 +331,7 @@ extern "C" int sd_lora_project(const void* plan_dev, const void* plan_host, void
     SdProfScope prof(SD_K_MISC, 0.0, st);
     SD_PROF_LABEL("lora_db_kernel<%d>", h->r_pad / 16);
     const int rc = pick_r(h->r_pad, [&](auto ks) {
-      hipLaunchKernelGGL(lora_db_kernel<decltype(ks)::value * 2>, dim3((h->db_items + 3) / 4), dim3(256), 0, st,
+      hipLaunchKernelGGL(lora_db_kernel<decltype(ks)::value * 2>, dim3(h->db_items), dim3(256), 0, st,
                          (const PlanHeader*)plan_dev);
       return 0;
     });

@@ -30,7 +30,7 @@ def _free_port():
     return p
 
 
-def _launch(world, per_device_batch, out, tag):
+def _launch(world, per_device_batch, out, tag, extra=()):
     port = _free_port()
     procs = []
     for rank in range(world):
@@ -45,6 +45,7 @@ def _launch(world, per_device_batch, out, tag):
                "--num_train_epochs", "1", "--logging_steps", "1", "--save_strategy", "no", "--learning_rate", "1e-3",
                "--warmup_steps", "0",
                "--output_dir", os.path.join(out, tag), "--log_json", os.path.join(out, tag + ".{rank}.json")]
+        cmd += list(extra)
         if world > 1:
             cmd += ["--ddp_backend", "gloo"]
         log = open(os.path.join(out, f"{tag}.{rank}.log"), "w")
@@ -92,4 +93,37 @@ def test_two_rank_train_script_equals_one_rank_on_the_concatenated_batch():
     gn_two = [e["grad_norm"] for e in r0["log_history"] if "grad_norm" in e]
     for a, b in zip(gn_one, gn_two):
         assert abs(a - b) <= 3e-2 * abs(a), (gn_one, gn_two)
+    assert loss0[-1] < loss0[0]
+
+
+def test_two_rank_lora_train_script_equals_one_rank():
+    """The same comparison with ``--use_lora`` (train.py:180-202): the data-parallel wrapper all-reduces the flat weight
+    gradient as always, every rank projects the SAME averaged dW onto its adapter (no atomics in sd_lora.hip), so the
+    adapters stay bitwise identical across ranks; only the adapter and the two saved modules train."""
+    out = tempfile.mkdtemp()
+    lora = ["--use_lora", "--lora_r", "8", "--lora_alpha", "16", "--init_lora_weights", "pissa"]
+    procs = _launch(2, 2, out, "lora2", lora) + _launch(1, 4, out, "lora1", lora)
+    for p, log in procs:
+        try:
+            rc = p.wait(timeout=900)
+        finally:
+            if p.poll() is None:
+                p.kill()
+            log.close()
+        assert rc == 0, open(log.name).read()[-4000:]
+    r0, r1 = (json.load(open(os.path.join(out, f"lora2.{r}.json"))) for r in range(2))
+    one = json.load(open(os.path.join(out, "lora1.0.json")))
+    with open(os.path.join(ROOT, "gpurun_out", "torchrun2_vs_1_lora.json"), "w") as f:
+        json.dump({"dp2_rank0": r0, "dp2_rank1": r1, "dp1": one}, f)
+    for r in (r0, r1, one):
+        assert r["optimizer"] == "FlatAdamW" and r["global_step"] == 4
+        assert r["trainable"] == ["embed_tokens", "lm_head", "lora_A", "lora_B"]
+    assert r0["reducer"] == {"backwards": 8, "synced": 4}
+    assert r0["adapter_checksum"] == r1["adapter_checksum"] and r0["param_checksum"] == r1["param_checksum"]
+    loss0 = [e["loss"] for e in r0["log_history"] if "loss" in e]
+    loss_one = [e["loss"] for e in one["log_history"] if "loss" in e]
+    assert len(loss0) == 4 and len(loss_one) == 4
+    for a, b in zip(loss_one, loss0):
+        assert abs(a - b) <= 5e-3 * abs(a), (loss_one, loss0)
+    assert abs(one["adapter_checksum"] - r0["adapter_checksum"]) <= 2e-3 * one["adapter_checksum"]
     assert loss0[-1] < loss0[0]
