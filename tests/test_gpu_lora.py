@@ -338,21 +338,61 @@ def test_lora_checkpoint_round_trip_and_merge(sda):
         assert torch.equal(plain(input_ids=ids).logits, ref)
 
 
-def test_lora_through_the_hf_trainer(sda):
-    """train.py:180-202 + :331-420 on the tiny config: a LoRA student inside DistillationTrainer (HF loop, gradient
-    accumulation 2, clipping, fused optimizer) trains, logs a finite gradient norm, and checkpoints its adapter."""
+def test_lora_through_the_hf_trainer_with_the_references_arguments(sda):
+    """train.py:180-202 + :331-420 on the tiny config with the reference's TrainingArguments (eval and checkpoint every
+    epoch, load_best_model_at_end, save_total_limit 3, gradient accumulation, clipping): the LoRA student trains through
+    the fused optimizer, every checkpoint is a peft-style adapter directory, and after train() the student holds the best
+    checkpoint's adapter bit for bit and evaluates to that checkpoint's eval loss."""
+    import numpy as np
+    from safetensors.torch import load_file
+    from transformers import TrainingArguments
     import test_gpu_model as M
     from speech_distill_amd import lora as L
+    from speech_distill_amd.collator import ProcessedDataCollator
     from speech_distill_amd.optim import FlatAdamW
-    tr, student, coll, feats, z = M._trainer(sda, 16, epochs=4, lr=2e-3)
-    lora_student = L.get_lora_model(student, L.LoraConfig(r=8, lora_alpha=16, init_lora_weights="pissa"))
-    tr.model = tr.model_wrapped = lora_student
-    tr.args.save_strategy = "no"
-    out = tr.train()
-    assert isinstance(tr.optimizer.optimizer if hasattr(tr.optimizer, "optimizer") else tr.optimizer, FlatAdamW)
+    from speech_distill_amd.trainer import DistillationTrainer
+    z, st, te, sw, tw, feats, pad, bos = M._c1(sda)
+    student, teacher = M._build(sda, st, sw), M._build(sda, te, tw)
+    teacher.eval().requires_grad_(False)
+    student = L.get_lora_model(student, L.LoraConfig(r=8, lora_alpha=16, init_lora_weights="pissa"))
+    out = tempfile.mkdtemp()
+    args = TrainingArguments(
+        output_dir=out, per_device_train_batch_size=4, per_device_eval_batch_size=4, gradient_accumulation_steps=2,
+        num_train_epochs=4, learning_rate=2e-3, logging_steps=1, eval_strategy="epoch", save_strategy="epoch",
+        load_best_model_at_end=True, save_total_limit=3, gradient_checkpointing=True, report_to=[],
+        remove_unused_columns=False, label_names=["labels"], seed=42, data_seed=42, lr_scheduler_type="constant",
+        warmup_steps=0, weight_decay=0.0, max_grad_norm=1.0, dataloader_num_workers=0, bf16=True)
+
+    class DS(torch.utils.data.Dataset):
+        def __init__(self, rows):
+            self.rows = rows
+
+        def __len__(self):
+            return len(self.rows)
+
+        def __getitem__(self, i):
+            return dict(self.rows[i])
+    coll = ProcessedDataCollator(M._Tok(pad, bos), pad_token_id=pad)
+    tr = DistillationTrainer(model=student, args=args, train_dataset=DS(feats), eval_dataset=DS(feats[:4]),
+                             data_collator=coll, teacher_model=teacher, temperature=2.0, alpha=0.5, top_k=16)
+    tr.train()
+    assert isinstance(getattr(tr.optimizer, "optimizer", tr.optimizer), FlatAdamW)
     hist = [h for h in tr.state.log_history if "loss" in h and "grad_norm" in h]
-    assert hist and all(math.isfinite(h["grad_norm"]) and h["grad_norm"] > 0 for h in hist)
+    assert len(hist) == 4 and all(math.isfinite(h["grad_norm"]) and h["grad_norm"] > 0 for h in hist)
     assert hist[-1]["loss"] < hist[0]["loss"], hist
-    d = tempfile.mkdtemp()
-    tr.save_model(d)
-    assert os.path.isfile(os.path.join(d, "adapter_model.safetensors")) and not os.path.exists(os.path.join(d, "model.safetensors"))
+    evals = [h["eval_loss"] for h in tr.state.log_history if "eval_loss" in h]
+    assert len(evals) == 4 and all(np.isfinite(evals)) and evals[-1] < evals[0]
+    ckpts = sorted(d for d in os.listdir(out) if d.startswith("checkpoint-"))
+    assert len(ckpts) == 3, ckpts
+    for c in ckpts:
+        files = set(os.listdir(os.path.join(out, c)))
+        assert {"adapter_config.json", "adapter_model.safetensors", "optimizer.pt", "trainer_state.json"} <= files
+        assert "model.safetensors" not in files
+    best = tr.state.best_model_checkpoint
+    assert best is not None and os.path.basename(best) in ckpts
+    sd = load_file(os.path.join(best, "adapter_model.safetensors"))
+    for k, v in student.state_dict().items():
+        assert torch.equal(v.cpu(), sd[k]), k
+    ev = tr.evaluate()
+    record("lora_trainer", losses=[h["loss"] for h in hist], evals=evals, final_eval=ev["eval_loss"])
+    assert abs(ev["eval_loss"] - min(evals)) <= 1e-6 + 1e-3 * abs(min(evals))
