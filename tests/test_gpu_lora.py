@@ -50,6 +50,8 @@ def test_lora_merge_and_project_kernels(sda, r_pad):
     from speech_distill_amd import _lib
     g = torch.Generator().manual_seed(r_pad)
     shapes = [(512, 256), (256, 256), (256, 256), (256, 512), (768, 256), (768, 256), (256, 768), (32, 128), (416, 384)]
+    if r_pad == 32:   # the student's real projection shapes (q, k/v, gate/up, down, o)
+        shapes += [(2048, 1024), (1024, 1024), (3072, 1024), (1024, 3072), (1024, 2048)]
     scale = 64 / math.sqrt(r_pad)
     T = []
     for out_f, in_f in shapes:
