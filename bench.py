@@ -218,6 +218,8 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="single stream everywhere (clean per-kernel profiles)")
     ap.add_argument("--no-traffic", action="store_true",
                     help="skip the live `roofline.traffic` measurement (two child runs of this script under rocprofv3 --pmc)")
+    ap.add_argument("--no-shared-hint", action="store_true",
+                    help="A/B: the two overlapped forwards are NOT told that they share the GPU (no SD_FWD_CONCURRENT)")
     ap.add_argument("--no-fold", action="store_true",
                     help="A/B: the frozen teacher runs its RMSNorm launches instead of folding the gains into the weights")
     ap.add_argument("--experiment-cu-hog", type=int, default=0, metavar="N",
@@ -276,9 +278,9 @@ def main():
         student.overlap_dw = False
     side = None if args.serial_teacher else ops.concurrent_stream(dev, "teacher")  # as DistillationTrainer does
 
-    def teacher_topk(rows):
+    def teacher_topk(rows, shared=False):
         t_logits = teacher(input_ids=batch["teacher_input_ids"], attention_mask=batch["teacher_attention_mask"],
-                           logit_rows=rows).logits                                          # train.py:60-69
+                           logit_rows=rows, concurrent=shared).logits                       # train.py:60-69
         return ops.logsoftmax_topk(t_logits, args.top_k, VOCAB)                             # train.py:80-91
 
     phase_ev = []
@@ -316,9 +318,11 @@ def main():
             else:  # the frozen teacher is independent of the student: run it on a second HIP stream
                 side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(side):
-                    tv, ti = teacher_topk(rows)
+                    tv, ti = teacher_topk(rows, shared=not args.no_shared_hint)
+        # both passes are told that they share the GPU (SD_FWD_CONCURRENT), as DistillationTrainer.compute_loss does
+        shared = side is not None and overlap and not args.experiment_pipeline and not args.no_shared_hint
         logits = student(input_ids=batch["input_ids"], attention_mask=batch["attention_mask"],
-                         labels=batch["labels"], logit_rows=rows).logits                    # train.py:54
+                         labels=batch["labels"], logit_rows=rows, concurrent=shared).logits  # train.py:54
         mark()
         if side is not None and overlap:
             torch.cuda.current_stream().wait_stream(side)

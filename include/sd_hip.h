@@ -296,6 +296,11 @@ typedef struct {
 #define SD_SAVE_ALL 1
 #define SD_SAVE_LAYER_INPUTS 2
 #define SD_SAVE_NONE_FOLDED 3
+/* OR-ed into `save` of sd_qwen3_forward(_rows): the caller runs ANOTHER pass beside this one on a second stream (the frozen
+ * teacher beside the student's forward, train.py:60-69 vs :54).  Launches are then sized for CU-time per FLOP instead of
+ * for covering every CU on their own (larger tiles on fewer workgroups for the N = hidden projections); results agree with
+ * the unflagged pass to bf16 rounding.  Without a second stream the flag costs time: leave it off for a pass that runs alone. */
+#define SD_FWD_CONCURRENT 0x100
 int sd_qwen3_fold_supported(const sd_qwen3_dims* d);
 /* bytes of activation storage for `sd_qwen3_forward` in that mode (negative: SD_ERR_* for an unknown mode) */
 int64_t sd_qwen3_acts_bytes(const sd_qwen3_dims* d, int B, int T, int save_for_backward);

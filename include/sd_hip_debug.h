@@ -7,6 +7,10 @@
  *   key                        default  meaning
  *   gemm.force_bm / force_nst  0 / 0    force tile rows (64|128|256) and LDS ring depth (2..4; 9 = the staggered 256x128
  *                                       family) of every later sd_gemm_* call; 0 / 0 = the dispatch heuristic
+ *   gemm.fwd_bump              0        tiles of a forward that shares the GPU with a second stream (SD_FWD_CONCURRENT,
+ *                                       sd_hip.h): 0 = follow the caller's flag (then bits 0|1); -1 = never; > 0 = force
+ *                                       these bits on every call, flagged or not -- bit0: forward + residual GEMMs 64 -> 128
+ *                                       rows, bit1: 128 -> 256, bit2 / bit3: the same for the dX GEMMs, bit4: 64 -> 256
  *   gemm.checked_staging       0        pointer staging with a zero page instead of buffer descriptors
  *   gemm.p256_unpaired         0        gemm_p256_kernel with 32-deep half-line stages (round-2 form)
  *   gemm.cu_budget             0        workgroups of the backward's persistent weight-gradient launches; 0 = one per CU.

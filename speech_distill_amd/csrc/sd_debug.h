@@ -14,6 +14,10 @@ struct SdDebug {
   int gemm_tn_stag_min = 1024;
   int gemm_splitk_min_kt = 96, gemm_splitk_min_slice = 24;
   int gemm_no_table = 0;  // ignore the measured shape -> variant table (sd_gemm_table.inc)
+  // tiles of a pass that shares the GPU with another stream (SD_FWD_CONCURRENT): 0 = follow the caller's flag (then bits
+  // 0|1), -1 = never, > 0 = force these bits on every call: bit0 forward + residual GEMMs 64 -> 128 rows, bit1 128 -> 256,
+  // bit2 / bit3 the same for the dX GEMMs, bit4 64 -> 256
+  int gemm_fwd_bump = 0;
   // sd_model.hip
   int model_fuse_student_swiglu = 0;
   int model_overlap_mask = 31;  // bit0 lm_head dW, bit1 gain reduces, bit2 attention dQ, bit3 grouped per-layer dW, bit4 batched gain reduce
@@ -23,3 +27,12 @@ struct SdDebug {
   int attn_variant = 0;  // bit0: forward without the in-wave pipeline at any T; bit1: with it at any T
 };
 extern SdDebug g_sd_debug;
+
+// Set by the model runner while it enqueues a forward that the caller runs BESIDE another pass on a second stream
+// (SD_FWD_CONCURRENT, include/sd_hip.h); read by the GEMM dispatch.  Per host thread, like the launches themselves.
+extern thread_local int t_sd_shared_gpu;
+struct SdSharedGpuScope {
+  int prev;
+  explicit SdSharedGpuScope(int on) : prev(t_sd_shared_gpu) { t_sd_shared_gpu = on; }
+  ~SdSharedGpuScope() { t_sd_shared_gpu = prev; }
+};

@@ -1664,6 +1664,23 @@ int dispatch(const void* A, const void* B, void* C, const void* R, float* slabs,
       }
   }
   if (g_sd_debug.gemm_force_bm) { bm = g_sd_debug.gemm_force_bm; nst = g_sd_debug.gemm_force_nst; }
+  // A pass that shares the GPU with a second stream (SD_FWD_CONCURRENT: the frozen teacher beside the student's forward)
+  // is not served by tiles chosen to cover all 256 CUs: what counts then is CU-time per FLOP, and the other stream fills
+  // whatever this launch leaves free.  The forward GEMMs that end in a residual add (o / down projections: N = hidden,
+  // 256 tiles of 64 x 128 for the student, of 128 x 128 for the teacher) take the next tile up -- half as many workgroups
+  // at 1.5x / 1.33x the FLOPs per staged byte: 20.46 -> 19.99 ms per config-2 step, alternating in one process
+  // (tests/bench_knob_ab.py); 64 -> 256 rows and the dX GEMMs measured neutral or worse.
+  const int bump = g_sd_debug.gemm_fwd_bump > 0 ? g_sd_debug.gemm_fwd_bump
+                                                : (g_sd_debug.gemm_fwd_bump == 0 && t_sd_shared_gpu ? 3 : 0);
+  if (bump && !ta && !tb && R && !slabs && epi_kind <= 1) {
+    if (bm == 64 && (bump & 16)) { bm = 256; nst = 9; }
+    else if (bm == 64 && (bump & 1)) { bm = 128; nst = 3; }
+    else if (bm == 128 && (bump & 2)) { bm = 256; nst = 9; }
+  }
+  if ((bump & 12) && !ta && tb && !slabs && splits == 1) {    // (measurement only) the same for the dX GEMMs
+    if (bm == 64 && (bump & 4)) { bm = 128; nst = 3; }
+    else if (bm == 128 && (bump & 8)) { bm = 256; nst = 9; }
+  }
   // the staggered kernel only has the descriptor staging path
   bool stag_ok = !g_sd_debug.gemm_checked_staging && (ta || tb || (K % BK) == 0) &&
                        ((long)K * (ta ? lda : 1) + (long)M * (ta ? 1 : lda)) * 2 < 0x70000000L &&

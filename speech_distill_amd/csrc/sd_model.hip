@@ -203,6 +203,7 @@ extern "C" int sd_qwen3_fold_supported(const sd_qwen3_dims* d) { return d && fol
 
 extern "C" int64_t sd_qwen3_acts_bytes(const sd_qwen3_dims* d, int B, int T, int save) {
   Sizes s(d, B, T);
+  save &= ~SD_FWD_CONCURRENT;
   if (save < SD_SAVE_NONE || save > SD_SAVE_NONE_FOLDED) return SD_ERR_SHAPE;
   if (save == SD_SAVE_NONE_FOLDED) return fold_supported(d) ? s.body(SD_SAVE_NONE) + s.tail() + 2 * s.ssq() : SD_ERR_UNSUPPORTED;
   return s.body(save) + s.tail();
@@ -229,6 +230,8 @@ extern "C" int sd_qwen3_forward_rows(const sd_qwen3_dims* d, const sd_qwen3_para
   if (B <= 0 || T <= 0) return SD_ERR_SHAPE;
   if (head_rows && (n_head_rows <= 0 || n_head_rows > B * T)) return SD_ERR_SHAPE;
   Sizes s(d, B, T);
+  SdSharedGpuScope shared((save & SD_FWD_CONCURRENT) ? 1 : 0);  // read by the GEMM dispatch for every launch below
+  save &= ~SD_FWD_CONCURRENT;
   if (save < SD_SAVE_NONE || save > SD_SAVE_NONE_FOLDED) return SD_ERR_SHAPE;
   const bool folded = save == SD_SAVE_NONE_FOLDED;
   if (folded) {

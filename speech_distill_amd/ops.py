@@ -51,7 +51,11 @@ def concurrent_stream(device, role):
         return _SIDE_STREAMS[key]
     with torch.cuda.device(device):
         main = torch.cuda.current_stream()
-        chosen = torch.cuda.Stream()
+        prio = int(os.environ.get("SD_STREAM_PRIORITY_" + role.upper(), "0"))  # measurement: -1 = high
+
+        def new_stream():
+            return torch.cuda.Stream(priority=prio)
+        chosen = new_stream()
         if os.environ.get("SD_STREAM_PICK", "1") != "0":
             peers = [_SIDE_STREAMS[(key[0], r)] for r in _ROLES_ACTIVE_TOGETHER[role] if (key[0], r) in _SIDE_STREAMS]
             fallback = None
@@ -60,7 +64,7 @@ def concurrent_stream(device, role):
                     if all(streams_overlap(p, chosen) for p in peers):
                         break
                     fallback = fallback or chosen
-                chosen = torch.cuda.Stream()
+                chosen = new_stream()
             else:
                 chosen = fallback or chosen  # no stream clear of every peer: at least clear of the main stream
     _SIDE_STREAMS[key] = chosen

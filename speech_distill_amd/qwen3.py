@@ -100,14 +100,15 @@ class CausalLMOutput(dict):
 
 
 SAVE_NONE, SAVE_ALL, SAVE_LAYER_INPUTS, SAVE_NONE_FOLDED = 0, 1, 2, 3  # include/sd_hip.h SD_SAVE_*
+FWD_CONCURRENT = 0x100                            # SD_FWD_CONCURRENT
 BWD_ACCUMULATE, BWD_RECOMPUTE = 1, 2              # SD_BWD_*
 
 
 class _DecoderFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, anchor, input_ids, kv_len, model, rows):
+    def forward(ctx, anchor, input_ids, kv_len, model, rows, concurrent=False):
         save = SAVE_LAYER_INPUTS if model._wants_recompute(*input_ids.shape, input_ids.device) else SAVE_ALL
-        logits, acts = model._run_forward(input_ids, kv_len, save=save, rows=rows)
+        logits, acts = model._run_forward(input_ids, kv_len, save=save, rows=rows, concurrent=concurrent)
         ctx.model, ctx.acts, ctx.ids, ctx.kv_len, ctx.rows, ctx.save = model, acts, input_ids, kv_len, rows, save
         return logits
 
@@ -116,7 +117,7 @@ class _DecoderFn(torch.autograd.Function):
         ctx.model._run_backward(ctx.ids, ctx.kv_len, ctx.acts, dlogits, rows=ctx.rows,
                                 recompute=ctx.save == SAVE_LAYER_INPUTS)
         ctx.acts = None
-        return torch.zeros((), device=dlogits.device), None, None, None, None
+        return torch.zeros((), device=dlogits.device), None, None, None, None, None
 
 
 class HipQwen3ForCausalLM(nn.Module):
@@ -477,7 +478,7 @@ class HipQwen3ForCausalLM(nn.Module):
         self._folded = (ver, buf, params, layers)
         return params
 
-    def _run_forward(self, input_ids, kv_len, save, rows=None):
+    def _run_forward(self, input_ids, kv_len, save, rows=None, concurrent=False):
         lib = load_lib()
         B, T = input_ids.shape
         dev = input_ids.device
@@ -497,7 +498,8 @@ class HipQwen3ForCausalLM(nn.Module):
             logits = torch.empty(rows.numel(), self.dims.vocab_size, dtype=torch.bfloat16, device=dev)
         check(lib.sd_qwen3_forward_rows(C.byref(self._cdims), C.byref(cparams), input_ids.data_ptr(), _p(kv_len),
                                         cos.data_ptr(), sin.data_ptr(), acts.data_ptr(), nbytes, logits.data_ptr(),
-                                        _p(rows), 0 if rows is None else rows.numel(), B, T, int(save), _stream()),
+                                        _p(rows), 0 if rows is None else rows.numel(), B, T,
+                                        int(save) | (FWD_CONCURRENT if concurrent else 0), _stream()),
               "sd_qwen3_forward_rows")
         return logits, acts
 
@@ -593,7 +595,9 @@ class HipQwen3ForCausalLM(nn.Module):
         """Returns an object with ``.logits`` [B,T,V] (bf16).  ``labels`` is accepted and ignored: the
         reference leaves it in ``inputs`` at train.py:54, which only makes HF compute an unused CE.
         ``logit_rows`` (int64 [R], flat b*T+t indices, unique): apply the lm_head to those rows only and return
-        ``.logits`` [R,V] -- the training step passes the rows the loss reads (``ops.loss_rows``)."""
+        ``.logits`` [R,V] -- the training step passes the rows the loss reads (``ops.loss_rows``).
+        ``concurrent=True`` (keyword): the caller runs another pass beside this one on a second stream (the frozen
+        teacher beside the student, as DistillationTrainer does): SD_FWD_CONCURRENT, launches sized for a shared GPU."""
         ids = _need(input_ids.to(torch.int64), torch.int64, "input_ids")
         rows = None
         if logit_rows is not None:
@@ -610,9 +614,10 @@ class HipQwen3ForCausalLM(nn.Module):
                                  "valid-prefix length per sequence, as ProcessedDataCollator produces (data.py:280-327)")
             kv_len = am.sum(-1).to(torch.int32).contiguous()
         if torch.is_grad_enabled() and (self._lora is not None or any(p.requires_grad for p in self._params.values())):
-            logits = _DecoderFn.apply(self._anchor, ids, kv_len, self, rows)
+            logits = _DecoderFn.apply(self._anchor, ids, kv_len, self, rows, bool(kwargs.get("concurrent", False)))
         else:
-            logits, _ = self._run_forward(ids, kv_len, save=SAVE_NONE, rows=rows)
+            logits, _ = self._run_forward(ids, kv_len, save=SAVE_NONE, rows=rows,
+                                          concurrent=bool(kwargs.get("concurrent", False)))
         return CausalLMOutput(logits=logits)
 
     def zero_grad(self, set_to_none: bool = True):

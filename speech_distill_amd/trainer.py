@@ -213,6 +213,10 @@ class DistillationTrainer(Trainer):
                 self._teacher_stream = ops.concurrent_stream(ids.device, "teacher")
             side = self._teacher_stream
             side.wait_stream(torch.cuda.current_stream())
+            # two passes share the GPU from here to the loss: both are told (SD_FWD_CONCURRENT, include/sd_hip.h)
+            teacher_kw = dict(teacher_kw, concurrent=True)
+            if hip_student:
+                checked = dict(checked, concurrent=True)
             with torch.cuda.stream(side):
                 teacher_logits, teacher_top_k_v, teacher_top_k_i = self._teacher_pass(
                     inputs, teacher_input_ids, teacher_attention_mask, vocab, rows, teacher_kw)
@@ -221,7 +225,7 @@ class DistillationTrainer(Trainer):
             teacher_top_k_v = teacher_top_k_v.to(dev).reshape(-1, teacher_top_k_v.size(-1))[rows]
             teacher_top_k_i = teacher_top_k_i.to(dev).reshape(-1, teacher_top_k_i.size(-1))[rows]
 
-        outputs = model(**inputs) if rows is None else model(**inputs, logit_rows=rows, **checked)  # train.py:54
+        outputs = model(**inputs, **checked) if rows is None else model(**inputs, logit_rows=rows, **checked)  # train.py:54
         student_logits = outputs.logits
         labels = inputs.pop("labels", None)
 

@@ -97,9 +97,9 @@ def main():
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 tl = teacher(input_ids=batch["teacher_input_ids"], attention_mask=batch["teacher_attention_mask"],
-                             logit_rows=rows).logits
+                             logit_rows=rows, concurrent=True).logits
                 tv, ti = ops.logsoftmax_topk(tl, 128, VOCAB)
-        logits = model(input_ids=batch["input_ids"], attention_mask=batch["attention_mask"], logit_rows=rows).logits
+        logits = model(input_ids=batch["input_ids"], attention_mask=batch["attention_mask"], logit_rows=rows, concurrent=True).logits
         torch.cuda.current_stream().wait_stream(side)
         total_loss = loss_fn.forward_rows(logits, row_labels, teacher_top_k_v=tv, teacher_top_k_i=ti)[0]
         (total_loss / args.accum).backward()

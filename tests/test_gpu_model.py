@@ -628,3 +628,47 @@ def test_flat_adamw_matches_torch_adamw(sda):
         # keep both trajectories on the same weights (the test is of one update, repeated)
     for rp, (k, p) in zip(ref_p, model._params.items()):
         mx, rms = check_close(f"flat_adamw_{k.split('.')[-2]}", p, rp, 3e-2, 1e-2)
+
+
+def test_shared_gpu_hint_changes_tiles_not_results(sda):
+    """SD_FWD_CONCURRENT (``model(..., concurrent=True)``: the caller runs another pass beside this one, as the trainer
+    does with the frozen teacher): the N = hidden projections take the next tile up -- fewer, higher-intensity
+    workgroups -- and nothing else changes.  Student-shaped training forward (64 -> 128 rows) with its backward, and the
+    frozen, norm-folded teacher-shaped inference forward (128 -> 256 rows, the epilogue that also emits the per-tile
+    sums of squares): same logits / gradients to bf16 rounding, different kernels."""
+    from speech_distill_amd import ops
+    ids = torch.randint(0, 2048, (4, 512), device=dev())
+    # student shape, trainable
+    model = sda.HipQwen3ForCausalLM(sda.Qwen3Dims(2048, 1024, 3072, 2, 16, 8), device=dev(), seed=5)
+    probe = torch.randn(4 * 512, 2048, device=dev()) * 0.01
+    res = {}
+    for flag in (False, True):
+        model.zero_grad()
+        ops.prof_begin()
+        logits = model(input_ids=ids, concurrent=flag).logits
+        ops.prof_end()
+        res[flag] = (logits.detach().clone(), {k: v[2] for k, v in ops.prof_symbols().items()})
+        (logits.float().view(-1, 2048) * probe).sum().backward()
+        res[flag] += (model.flat_grad.clone(),)
+    (la, ka, ga), (lb, kb, gb) = res[False], res[True]
+    small = sum(n for k, n in ka.items() if k.startswith("gemm_bf16_kernel<64,") and "false, false, 1" in k)
+    assert small == 4 and not any(k.startswith("gemm_bf16_kernel<64,") and "false, false, 1" in k for k in kb), (ka, kb)
+    assert sum(n for k, n in kb.items() if k.startswith("gemm_bf16_kernel<128,") and "false, false, 1" in k) == 4, kb
+    check_close("shared_hint_student_logits", lb, la, 1e-2, 1e-3)
+    check_close("shared_hint_student_grads", gb, ga.double(), 2e-2, 2e-3)
+    # teacher shape, frozen: folded norms, o / down projections write the sums of squares in their epilogue
+    teacher = sda.HipQwen3ForCausalLM(sda.Qwen3Dims(2048, 2048, 6144, 2, 16, 8, tie_word_embeddings=False), device=dev(), seed=6)
+    teacher.eval().requires_grad_(False)
+    out = {}
+    with torch.no_grad():
+        for flag in (False, True):
+            ops.prof_begin()
+            out[flag] = teacher(input_ids=ids, concurrent=flag).logits
+            ops.prof_end()
+            out[flag] = (out[flag], {k: v[2] for k, v in ops.prof_symbols().items()})
+    assert teacher._folded is not None
+    (ta, sa), (tb, sb) = out[False], out[True]
+    assert sum(n for k, n in sa.items() if k.startswith("gemm_bf16_kernel<128,") and "false, false, 1" in k) == 4, sa
+    assert not any(k.startswith("gemm_bf16_kernel<128,") and "false, false, 1" in k for k in sb), sb
+    assert sum(n for k, n in sb.items() if k.startswith("gemm_stag_kernel<false, false, 1>")) == 4, sb
+    check_close("shared_hint_teacher_logits", tb, ta, 1e-2, 1e-3)
