@@ -13,7 +13,9 @@
  *                                       rows, bit1: 128 -> 256, bit2 / bit3: the same for the dX GEMMs, bit4: 64 -> 256
  *   gemm.checked_staging       0        pointer staging with a zero page instead of buffer descriptors
  *   gemm.p256_unpaired         0        gemm_p256_kernel with 32-deep half-line stages (round-2 form)
- *   gemm.cu_budget             0        workgroups of the backward's persistent weight-gradient launches; 0 = one per CU.
+ *   gemm.cu_budget             0        workgroups of the backward's persistent weight-gradient launches; 0 = three quarters
+ *                                       of the CUs when they run on the side stream beside the dX chain, else one per CU;
+ *                                       -1 = one per CU always.
  *                                       A multi-GPU run where RCCL's kernels hold CUs beside the backward may set 240
  *                                       (speech_distill_amd/ddp.py forwards SD_GEMM_CU_BUDGET)
  *   gemm.no_persist / no_p256  0 / 0    never dispatch the persistent 256x128 / 256x256 kernels
@@ -24,6 +26,9 @@
  *   gemm.splitk_min_slice      24       least K/64 per slice (clamped to >= 1)
  *   gemm.no_table              0        ignore the measured shape -> variant table (csrc/sd_gemm_table.inc): heuristic only
  *   model.fuse_student_swiglu  0        SwiGLU in the gate|up GEMM epilogue also when gate|up is kept for the backward
+ *   model.shared_layers        -1       decoder layers of a SD_FWD_CONCURRENT INFERENCE forward (the teacher) that run with the
+ *                                       shared-GPU tiles; the rest run as if alone (-1 = all).  model.shared_layers_train: the
+ *                                       same for a forward that saves activations (the student)
  *   model.overlap_mask         31       sd_qwen3_backward: bit0 lm_head dW, bit1 gain reduces, bit2 attention dQ on the side
  *                                       stream, bit3 grouped per-layer dW, bit4 one batched gain reduce per layer
  *   topk.nt                    0        threads per row of topk_kernel (256|512|1024; 0 = 512)

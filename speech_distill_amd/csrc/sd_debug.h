@@ -7,7 +7,7 @@ struct SdDebug {
   int gemm_force_bm = 0, gemm_force_nst = 0;  // 0 = heuristic; else tile rows (64|128|256) and ring depth (2..4, 9 = staggered)
   int gemm_checked_staging = 0;               // pointer-based staging with a zero page instead of buffer descriptors
   int gemm_p256_unpaired = 0;                 // gemm_p256_kernel with 32-deep half-line stages
-  int gemm_cu_budget = 0;                     // workgroups of the backward's persistent weight-gradient launches (0 = one per CU)
+  int gemm_cu_budget = 0;                     // workgroups of the backward's persistent weight-gradient launches (0 = 3/4 of the CUs beside the dX chain, -1 = all)
   int gemm_no_persist = 0, gemm_no_p256 = 0;
   int gemm_p256_min_tiles = 1024;
   int gemm_group_m = 0;
@@ -20,6 +20,8 @@ struct SdDebug {
   int gemm_fwd_bump = 0;
   // sd_model.hip
   int model_fuse_student_swiglu = 0;
+  // decoder layers of a SD_FWD_CONCURRENT forward that are run with the shared-GPU tiles (-1 = all): inference / training pass
+  int model_shared_layers = -1, model_shared_layers_train = -1;
   int model_overlap_mask = 31;  // bit0 lm_head dW, bit1 gain reduces, bit2 attention dQ, bit3 grouped per-layer dW, bit4 batched gain reduce
   // sd_topk.hip / sd_elementwise.hip / sd_attn.hip
   int topk_nt = 0;

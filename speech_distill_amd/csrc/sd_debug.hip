@@ -27,6 +27,8 @@ const Key kKeys[] = {
     {"gemm.fwd_bump", &SdDebug::gemm_fwd_bump},
     {"model.fuse_student_swiglu", &SdDebug::model_fuse_student_swiglu},
     {"model.overlap_mask", &SdDebug::model_overlap_mask},
+    {"model.shared_layers", &SdDebug::model_shared_layers},
+    {"model.shared_layers_train", &SdDebug::model_shared_layers_train},
     {"topk.nt", &SdDebug::topk_nt},
     {"qk_bwd.blocks", &SdDebug::qk_bwd_blocks},
     {"attn.variant", &SdDebug::attn_variant},

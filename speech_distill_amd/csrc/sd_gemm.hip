@@ -1486,7 +1486,15 @@ void* g_stamp_buffer = nullptr;  // diagnostic build: device buffer for the phas
 // gradient) take one workgroup per CU for their whole duration; when RCCL's reduction kernels hold c CUs meanwhile, c
 // workgroups start only after others have finished and the launch takes up to twice as long (measured with
 // bench.py --experiment-cu-hog 16: +22 % / +70 %).  A budget of 256 - c keeps every workgroup resident from the start.
-static int cu_budget() { return g_sd_debug.gemm_cu_budget > 0 ? (g_sd_debug.gemm_cu_budget & ~7) : 0; }
+// Default (knob 0): when the backward runs them on its side stream beside the dX chain (t_sd_shared_gpu, set by the
+// runner), three quarters of the CUs -- the chain's kernels then always find CUs instead of queueing behind a launch
+// that holds every one of them for 70-550 us: 19.51 -> 19.31 ms per config-2 step and half the run-to-run spread
+// (tests/bench_knob_ab.py gemm.cu_budget 0 192, alternating in one process; 224 / 160 / 128 measured no better).
+// Knob -1: one workgroup per CU whatever the runner says.
+static int cu_budget(int cus = 256) {
+  if (g_sd_debug.gemm_cu_budget > 0) return g_sd_debug.gemm_cu_budget & ~7;
+  return (g_sd_debug.gemm_cu_budget == 0 && t_sd_shared_gpu) ? ((cus * 3 / 4) & ~7) : 0;
+}
 thread_local bool g_skip_reduce = false;  // set by sd_gemm_bf16_splitk_partial around its dispatch
 
 template <int BM, int NST, bool TA, bool TB>
@@ -1559,7 +1567,8 @@ int launch(const void* A, const void* B, void* C, const void* R, float* slabs, i
         SD_PROF_LABEL("gemm_pstag_kernel<4, %s, %s, %d>", TA ? "true" : "false", TB ? "true" : "false", EPI);          \
         SD_STAMP_ARGS();                                                                                               \
         /* weight gradients (TA): the backward's persistent launches honour the CU budget of a multi-GPU run */       \
-        const int pg = (TA && cu_budget() > 0 && cu_budget() < persist_grid) ? cu_budget() : persist_grid;             \
+        const int cb = cu_budget(persist_grid);                                                                        \
+        const int pg = (TA && cb > 0 && cb < persist_grid) ? cb : persist_grid;                                        \
         hipLaunchKernelGGL((gemm_pstag_kernel<4, TA, TB, EPI>), dim3(pg), dim3(768), 0, st, (const bf16*)A,            \
                            (const bf16*)B, (bf16*)C, (const bf16*)R, M, N, K, lda, ldb, ldc, ldr, tiles_m, tiles_n,    \
                            gm, SD_STAMP_EA);                                                                           \
@@ -1806,7 +1815,7 @@ extern "C" int sd_gemm_grouped_tn(const sd_gemm_problem* probs, int n, int K, in
     return SD_ERR_UNSUPPORTED;
   cus &= ~7;
   if (cus <= 0) return SD_ERR_UNSUPPORTED;
-  if (cu_budget() > 0 && cu_budget() < cus) cus = cu_budget();
+  if (const int cb = cu_budget(cus); cb > 0 && cb < cus) cus = cb;
   SdProfScope prof(SD_K_GEMM_TN, flops, (hipStream_t)stream);
   SD_PROF_LABEL("gemm_pgroup_tn_kernel<%s>", accumulate ? "true" : "false");
   // (sharing the DMA issue with the compute waves, gemm_pstag_kernel's +3 %, was measured 2-4 % SLOWER here -- 73.5-74.6 vs

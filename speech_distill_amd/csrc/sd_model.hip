@@ -230,7 +230,7 @@ extern "C" int sd_qwen3_forward_rows(const sd_qwen3_dims* d, const sd_qwen3_para
   if (B <= 0 || T <= 0) return SD_ERR_SHAPE;
   if (head_rows && (n_head_rows <= 0 || n_head_rows > B * T)) return SD_ERR_SHAPE;
   Sizes s(d, B, T);
-  SdSharedGpuScope shared((save & SD_FWD_CONCURRENT) ? 1 : 0);  // read by the GEMM dispatch for every launch below
+  const bool concurrent = (save & SD_FWD_CONCURRENT) != 0;
   save &= ~SD_FWD_CONCURRENT;
   if (save < SD_SAVE_NONE || save > SD_SAVE_NONE_FOLDED) return SD_ERR_SHAPE;
   const bool folded = save == SD_SAVE_NONE_FOLDED;
@@ -256,6 +256,9 @@ extern "C" int sd_qwen3_forward_rows(const sd_qwen3_dims* d, const sd_qwen3_para
   for (int l = 0; l < s.L; ++l) {
     LayerActs a = save ? layer_acts(s, base, l, save) : carve(s, base);
     a.x_in = x_cur;
+    // read by the GEMM dispatch for every launch of this layer ("model.shared_layers": measurement, sd_hip_debug.h)
+    const int lim = save ? g_sd_debug.model_shared_layers_train : g_sd_debug.model_shared_layers;
+    SdSharedGpuScope shared(concurrent && (lim < 0 || l < lim) ? 1 : 0);
     char* x_out;
     if (save) x_out = (l + 1 < s.L) ? layer_acts(s, base, l + 1, save).x_in : x_last;
     else x_out = (l + 1 < s.L) ? ((x_cur == pong) ? base : pong) : x_last;
@@ -320,6 +323,7 @@ extern "C" int sd_qwen3_backward_rows(const sd_qwen3_dims* d, const sd_qwen3_par
   if (s2 && !(lease.set = sd_lease_events())) return SD_ERR_WORKSPACE;
   hipEvent_t* g_ev = lease.set ? lease.set->ev : nullptr;  // this call's events
   void* wstream = s2 ? side_stream : stream;  // where weight-gradient GEMMs go
+  SdSharedGpuScope shared(s2 ? 1 : 0);  // two streams share the GPU: the persistent dW launches leave CUs to the dX chain
   // main -> side: "this buffer is final"; side -> main: "this layer's dW GEMMs have read their inputs"
 #define SIGNAL(i) do { if (s2) { if (hipEventRecord(g_ev[i], s1) != hipSuccess || hipStreamWaitEvent(s2, g_ev[i], 0) != hipSuccess) return SD_ERR_WORKSPACE; } } while (0)
 #define JOIN() do { if (s2) { if (hipEventRecord(g_ev[7], s2) != hipSuccess || hipStreamWaitEvent(s1, g_ev[7], 0) != hipSuccess) return SD_ERR_WORKSPACE; } } while (0)

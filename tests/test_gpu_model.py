@@ -398,8 +398,8 @@ def test_gradient_checkpointing_recompute_is_bit_identical(sda, layers):
     seen = []
     real_forward = model._run_forward
 
-    def spy(input_ids, kv_len, save, rows=None):
-        logits, acts = real_forward(input_ids, kv_len, save, rows=rows)
+    def spy(input_ids, kv_len, save, rows=None, **kw):
+        logits, acts = real_forward(input_ids, kv_len, save, rows=rows, **kw)
         seen.append((int(save), acts.numel()))
         return logits, acts
     model._run_forward = spy
