@@ -10,7 +10,9 @@
  *   gemm.fwd_bump              0        tiles of a forward that shares the GPU with a second stream (SD_FWD_CONCURRENT,
  *                                       sd_hip.h): 0 = follow the caller's flag (then bits 0|1); -1 = never; > 0 = force
  *                                       these bits on every call, flagged or not -- bit0: forward + residual GEMMs 64 -> 128
- *                                       rows, bit1: 128 -> 256, bit2 / bit3: the same for the dX GEMMs, bit4: 64 -> 256
+ *                                       rows, bit1: 128 -> 256, bit2 / bit3: the same for the dX GEMMs, bit4: 64 -> 256,
+ *                                       bit5 / bit6: the 128-row tile of bit0 / of the teacher with a 2-stage ring (two
+ *                                       workgroups per CU); bits 2-6 were measured and lost
  *   gemm.checked_staging       0        pointer staging with a zero page instead of buffer descriptors
  *   gemm.p256_unpaired         0        gemm_p256_kernel with 32-deep half-line stages (round-2 form)
  *   gemm.cu_budget             0        workgroups of the backward's persistent weight-gradient launches; 0 = three quarters

@@ -16,7 +16,7 @@ struct SdDebug {
   int gemm_no_table = 0;  // ignore the measured shape -> variant table (sd_gemm_table.inc)
   // tiles of a pass that shares the GPU with another stream (SD_FWD_CONCURRENT): 0 = follow the caller's flag (then bits
   // 0|1), -1 = never, > 0 = force these bits on every call: bit0 forward + residual GEMMs 64 -> 128 rows, bit1 128 -> 256,
-  // bit2 / bit3 the same for the dX GEMMs, bit4 64 -> 256
+  // bit2 / bit3 the same for the dX GEMMs, bit4 64 -> 256, bit5 / bit6 2-stage 128-row tiles (measurement)
   int gemm_fwd_bump = 0;
   // sd_model.hip
   int model_fuse_student_swiglu = 0;

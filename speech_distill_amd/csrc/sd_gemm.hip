@@ -1683,8 +1683,9 @@ int dispatch(const void* A, const void* B, void* C, const void* R, float* slabs,
                                                 : (g_sd_debug.gemm_fwd_bump == 0 && t_sd_shared_gpu ? 3 : 0);
   if (bump && !ta && !tb && R && !slabs && epi_kind <= 1) {
     if (bm == 64 && (bump & 16)) { bm = 256; nst = 9; }
-    else if (bm == 64 && (bump & 1)) { bm = 128; nst = 3; }
+    else if (bm == 64 && (bump & 1)) { bm = 128; nst = (bump & 32) ? 2 : 3; }
     else if (bm == 128 && (bump & 2)) { bm = 256; nst = 9; }
+    else if (bm == 128 && (bump & 64)) { nst = 2; }   // (measurement) 64 KiB of LDS: two workgroups per CU
   }
   if ((bump & 12) && !ta && tb && !slabs && splits == 1) {    // (measurement only) the same for the dX GEMMs
     if (bm == 64 && (bump & 4)) { bm = 128; nst = 3; }

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("values", nargs="+", type=int)
     ap.add_argument("--rounds", type=int, default=8)
     ap.add_argument("--block", type=int, default=10)
+    ap.add_argument("--cached-rows", action="store_true", help="select the loss rows once (no host read per step)")
     ap.add_argument("--main-priority", type=int, default=0, help="run the step on a stream of this priority (-1 = high)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
@@ -42,9 +43,15 @@ def main():
     batch = synthetic_batch(4, 512, 0, dev)
     side = ops.concurrent_stream(dev, "teacher")
 
+    cache = []
+
     def micro():
         student.zero_grad()
-        rows, row_labels = ops.loss_rows(batch["labels"])
+        if args.cached_rows and cache:
+            rows, row_labels = cache[0]
+        else:
+            rows, row_labels = ops.loss_rows(batch["labels"])
+            cache[:] = [(rows, row_labels)]
         with torch.no_grad():
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
