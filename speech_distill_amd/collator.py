@@ -12,7 +12,7 @@ fixture G3, ``tests/test_collator_golden.py``) --
   features carry pre-extracted top-K (data.py:330-348).
 
 Built differently from the reference: every ragged field becomes ONE scatter of its concatenated values into a
-pre-filled ``[B, W]`` grid (index vectors from the row lengths: no per-row copy loop, no per-row ``.item()``), and
+pre-filled ``[B, W]`` grid (a length mask selects the valid cells in row-major order: no per-row copy loop), and
 ``labels`` is one ``where`` over the grid instead of a clone masked twice.  Host-side only (dataloader workers).
 """
 from typing import Any, Dict, List, Optional, Sequence
@@ -24,12 +24,10 @@ def _ragged_to_grid(seqs: Sequence, width: int, fill, dtype) -> torch.Tensor:
     """Right-padded ``[len(seqs), width]`` grid of the ragged ``seqs`` (1-D each), one scatter."""
     lens = torch.tensor([len(s) for s in seqs], dtype=torch.long)
     grid = torch.full((len(seqs), width), fill, dtype=dtype)
-    total = int(lens.sum())
-    if total:
+    if int(lens.sum()):
         flat = torch.cat([torch.as_tensor(s, dtype=dtype).reshape(-1) for s in seqs])
-        row = torch.repeat_interleave(torch.arange(len(seqs)), lens)
-        col = torch.arange(total) - torch.repeat_interleave(torch.cumsum(lens, 0) - lens, lens)
-        grid[row, col] = flat
+        # row-major order of the valid cells = the order of the concatenation
+        grid[torch.arange(width)[None, :] < lens[:, None]] = flat
     return grid
 
 
