@@ -295,7 +295,13 @@ class HipDataParallel(torch.nn.Module):
         self.reducer = None
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
             if broadcast_params and getattr(module, "flat", None) is not None:
-                dist.broadcast(module.flat, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+                src = dist.get_global_rank(group, 0) if group is not None else 0
+                dist.broadcast(module.flat, src=src, group=group)
+                lora = getattr(module, "_lora", None)
+                if lora is not None:   # a LoRA student: rank 0's adapter and residual base too (lora.py)
+                    dist.broadcast(lora.master, src=src, group=group)
+                    dist.broadcast(lora.base, src=src, group=group)
+                    lora.refresh_shadows()
             self.reducer = attach(module, group, layers_per_bucket, split_embedding)
 
     def forward(self, *args, **kwargs):
