@@ -1,4 +1,8 @@
-# in-process A/Bs (tests/bench_knob_ab.py)
+# in-process A/Bs (tests/bench_knob_ab.py): the shared-GPU defaults (now shape-conditional) vs both off, over token counts
 cd $GRAFT_REPO_ROOT
-echo "dX 64 -> 128 rows under the default budget (3 = adopted forward bits, 7 = + dX bit)"
-python tests/bench_knob_ab.py gemm.fwd_bump 3 7 --rounds 14 --block 8 2>/dev/null
+for shape in "1 512" "2 512" "3 512" "4 512" "6 512" "8 512" "4 2048"; do
+  set -- $shape
+  echo "B=$1 T=$2: cu_budget -1 + fwd_bump -1 (both off, first value) vs defaults (second)"
+  SD_DEBUG="gemm.fwd_bump=-1" python tests/bench_knob_ab.py gemm.cu_budget -1 -1 --batch $1 --seq-len $2 --rounds 3 --block 5 2>/dev/null
+  python tests/bench_knob_ab.py gemm.cu_budget 0 0 --batch $1 --seq-len $2 --rounds 3 --block 5 2>/dev/null
+done

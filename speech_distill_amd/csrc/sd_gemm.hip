@@ -1490,10 +1490,13 @@ void* g_stamp_buffer = nullptr;  // diagnostic build: device buffer for the phas
 // runner), three quarters of the CUs -- the chain's kernels then always find CUs instead of queueing behind a launch
 // that holds every one of them for 70-550 us: 19.51 -> 19.31 ms per config-2 step and half the run-to-run spread
 // (tests/bench_knob_ab.py gemm.cu_budget 0 192, alternating in one process; 224 / 160 / 128 measured no better).
-// Knob -1: one workgroup per CU whatever the runner says.
-static int cu_budget(int cus = 256) {
+// Only for 1 536 .. 3 072 tokens per launch (K of a weight-gradient GEMM): measured -0.16 / -0.20 / -0.19 ms at 1 536 /
+// 2 048 / 3 072 tokens, +-0.0 at 1 024, +0.1 at 512, and +0.57 / +1.3 ms at 4 096 / 8 192, where the chain's own kernels
+// fill the chip for long stretches and the budget only slows the weight gradients.  Knob -1: one workgroup per CU always.
+static int cu_budget(int cus, int tokens) {
   if (g_sd_debug.gemm_cu_budget > 0) return g_sd_debug.gemm_cu_budget & ~7;
-  return (g_sd_debug.gemm_cu_budget == 0 && t_sd_shared_gpu) ? ((cus * 3 / 4) & ~7) : 0;
+  const bool in_range = tokens >= 1536 && tokens <= 3072;
+  return (g_sd_debug.gemm_cu_budget == 0 && t_sd_shared_gpu && in_range) ? ((cus * 3 / 4) & ~7) : 0;
 }
 thread_local bool g_skip_reduce = false;  // set by sd_gemm_bf16_splitk_partial around its dispatch
 
@@ -1567,7 +1570,7 @@ int launch(const void* A, const void* B, void* C, const void* R, float* slabs, i
         SD_PROF_LABEL("gemm_pstag_kernel<4, %s, %s, %d>", TA ? "true" : "false", TB ? "true" : "false", EPI);          \
         SD_STAMP_ARGS();                                                                                               \
         /* weight gradients (TA): the backward's persistent launches honour the CU budget of a multi-GPU run */       \
-        const int cb = cu_budget(persist_grid);                                                                        \
+        const int cb = cu_budget(persist_grid, K);                                                                     \
         const int pg = (TA && cb > 0 && cb < persist_grid) ? cb : persist_grid;                                        \
         hipLaunchKernelGGL((gemm_pstag_kernel<4, TA, TB, EPI>), dim3(pg), dim3(768), 0, st, (const bf16*)A,            \
                            (const bf16*)B, (bf16*)C, (const bf16*)R, M, N, K, lda, ldb, ldc, ldr, tiles_m, tiles_n,    \
@@ -1678,9 +1681,12 @@ int dispatch(const void* A, const void* B, void* C, const void* R, float* slabs,
   // whatever this launch leaves free.  The forward GEMMs that end in a residual add (o / down projections: N = hidden,
   // 256 tiles of 64 x 128 for the student, of 128 x 128 for the teacher) take the next tile up -- half as many workgroups
   // at 1.5x / 1.33x the FLOPs per staged byte: 20.46 -> 19.99 ms per config-2 step, alternating in one process
-  // (tests/bench_knob_ab.py); 64 -> 256 rows and the dX GEMMs measured neutral or worse.
+  // (tests/bench_knob_ab.py); 64 -> 256 rows and the dX GEMMs measured neutral or worse.  Only while
+  // the tile that covers the chip still yields >= 192 workgroups (>= 96 after the step up): -0.46 / -0.50 / -0.85 / -0.32 ms
+  // per step at 1 536 / 2 048 / 3 072 / 4 096 tokens, +-0.0 at 1 024 (128 -> 64 workgroups), +0.35 ms at 512 (64 -> 32).
+  const long tiles_now = (long)((M + bm - 1) / bm) * ((N + BN - 1) / BN);
   const int bump = g_sd_debug.gemm_fwd_bump > 0 ? g_sd_debug.gemm_fwd_bump
-                                                : (g_sd_debug.gemm_fwd_bump == 0 && t_sd_shared_gpu ? 3 : 0);
+                   : (g_sd_debug.gemm_fwd_bump == 0 && t_sd_shared_gpu && tiles_now >= 192 ? 3 : 0);
   if (bump && !ta && !tb && R && !slabs && epi_kind <= 1) {
     if (bm == 64 && (bump & 16)) { bm = 256; nst = 9; }
     else if (bm == 64 && (bump & 1)) { bm = 128; nst = (bump & 32) ? 2 : 3; }
@@ -1816,7 +1822,7 @@ extern "C" int sd_gemm_grouped_tn(const sd_gemm_problem* probs, int n, int K, in
     return SD_ERR_UNSUPPORTED;
   cus &= ~7;
   if (cus <= 0) return SD_ERR_UNSUPPORTED;
-  if (const int cb = cu_budget(cus); cb > 0 && cb < cus) cus = cb;
+  if (const int cb = cu_budget(cus, K); cb > 0 && cb < cus) cus = cb;
   SdProfScope prof(SD_K_GEMM_TN, flops, (hipStream_t)stream);
   SD_PROF_LABEL("gemm_pgroup_tn_kernel<%s>", accumulate ? "true" : "false");
   // (sharing the DMA issue with the compute waves, gemm_pstag_kernel's +3 %, was measured 2-4 % SLOWER here -- 73.5-74.6 vs

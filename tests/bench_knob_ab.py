@@ -23,6 +23,8 @@ def main():
     ap.add_argument("values", nargs="+", type=int)
     ap.add_argument("--rounds", type=int, default=8)
     ap.add_argument("--block", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=4)
+    ap.add_argument("--seq-len", type=int, default=512)
     ap.add_argument("--cached-rows", action="store_true", help="select the loss rows once (no host read per step)")
     ap.add_argument("--main-priority", type=int, default=0, help="run the step on a stream of this priority (-1 = high)")
     args = ap.parse_args()
@@ -40,7 +42,7 @@ def main():
     teacher, student = fresh(sda.Qwen3Dims.teacher_17b(), 1), fresh(sda.Qwen3Dims.student_06b(), 0)
     teacher.eval().requires_grad_(False)
     loss_fn = sda.DistillationLoss(temperature=2.0, alpha=0.5, inplace_grad=True)
-    batch = synthetic_batch(4, 512, 0, dev)
+    batch = synthetic_batch(args.batch, args.seq_len, 0, dev)
     side = ops.concurrent_stream(dev, "teacher")
 
     cache = []
