@@ -1,8 +1,6 @@
-# in-process A/Bs (tests/bench_knob_ab.py): the shared-GPU defaults (now shape-conditional) vs both off, over token counts
+# in-process A/Bs (tests/bench_knob_ab.py): which forward is enqueued first
 cd $GRAFT_REPO_ROOT
-for shape in "1 512" "2 512" "3 512" "4 512" "6 512" "8 512" "4 2048"; do
-  set -- $shape
-  echo "B=$1 T=$2: cu_budget -1 + fwd_bump -1 (both off, first value) vs defaults (second)"
-  SD_DEBUG="gemm.fwd_bump=-1" python tests/bench_knob_ab.py gemm.cu_budget -1 -1 --batch $1 --seq-len $2 --rounds 3 --block 5 2>/dev/null
-  python tests/bench_knob_ab.py gemm.cu_budget 0 0 --batch $1 --seq-len $2 --rounds 3 --block 5 2>/dev/null
+for i in 1 2; do
+echo "teacher first"; python tests/bench_knob_ab.py gemm.no_table 0 0 --rounds 4 --block 8 2>/dev/null
+echo "student first"; python tests/bench_knob_ab.py gemm.no_table 0 0 --rounds 4 --block 8 --student-first 2>/dev/null
 done

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--block", type=int, default=10)
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--seq-len", type=int, default=512)
+    ap.add_argument("--student-first", action="store_true", help="enqueue the student's forward before the teacher's")
     ap.add_argument("--cached-rows", action="store_true", help="select the loss rows once (no host read per step)")
     ap.add_argument("--main-priority", type=int, default=0, help="run the step on a stream of this priority (-1 = high)")
     args = ap.parse_args()
@@ -54,13 +55,18 @@ def main():
         else:
             rows, row_labels = ops.loss_rows(batch["labels"])
             cache[:] = [(rows, row_labels)]
-        with torch.no_grad():
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                tl = teacher(input_ids=batch["teacher_input_ids"], attention_mask=batch["teacher_attention_mask"],
-                             logit_rows=rows, concurrent=True).logits
-                tv, ti = ops.logsoftmax_topk(tl, 128, VOCAB)
+        def run_teacher():
+            with torch.no_grad():
+                with torch.cuda.stream(side):
+                    tl = teacher(input_ids=batch["teacher_input_ids"], attention_mask=batch["teacher_attention_mask"],
+                                 logit_rows=rows, concurrent=True).logits
+                    return ops.logsoftmax_topk(tl, 128, VOCAB)
+        side.wait_stream(torch.cuda.current_stream())
+        if not args.student_first:
+            tv, ti = run_teacher()
         logits = student(input_ids=batch["input_ids"], attention_mask=batch["attention_mask"], logit_rows=rows, concurrent=True).logits
+        if args.student_first:
+            tv, ti = run_teacher()
         torch.cuda.current_stream().wait_stream(side)
         loss_fn.forward_rows(logits, row_labels, teacher_top_k_v=tv, teacher_top_k_i=ti)[0].backward()
 
