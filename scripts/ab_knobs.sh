@@ -1,6 +1,3 @@
-# in-process A/Bs (tests/bench_knob_ab.py): which forward is enqueued first
+# in-process A/Bs (tests/bench_knob_ab.py): 256x256 tiles for the (unfolded) teacher's gate|up beside the student
 cd $GRAFT_REPO_ROOT
-for i in 1 2; do
-echo "teacher first"; python tests/bench_knob_ab.py gemm.no_table 0 0 --rounds 4 --block 8 2>/dev/null
-echo "student first"; python tests/bench_knob_ab.py gemm.no_table 0 0 --rounds 4 --block 8 --student-first 2>/dev/null
-done
+python tests/bench_knob_ab.py gemm.p256_min_tiles 1024 300 --no-fold --rounds 8 --block 8 2>/dev/null

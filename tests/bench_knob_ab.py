@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--seq-len", type=int, default=512)
     ap.add_argument("--student-first", action="store_true", help="enqueue the student's forward before the teacher's")
+    ap.add_argument("--no-fold", action="store_true", help="the teacher runs its RMSNorm launches (no folded gains)")
     ap.add_argument("--cached-rows", action="store_true", help="select the loss rows once (no host read per step)")
     ap.add_argument("--main-priority", type=int, default=0, help="run the step on a stream of this priority (-1 = high)")
     args = ap.parse_args()
@@ -42,6 +43,7 @@ def main():
         return m
     teacher, student = fresh(sda.Qwen3Dims.teacher_17b(), 1), fresh(sda.Qwen3Dims.student_06b(), 0)
     teacher.eval().requires_grad_(False)
+    teacher.fold_norm_gains = not args.no_fold
     loss_fn = sda.DistillationLoss(temperature=2.0, alpha=0.5, inplace_grad=True)
     batch = synthetic_batch(args.batch, args.seq_len, 0, dev)
     side = ops.concurrent_stream(dev, "teacher")
