@@ -24,6 +24,7 @@ const Key kKeys[] = {
     {"gemm.splitk_min_kt", &SdDebug::gemm_splitk_min_kt},
     {"gemm.splitk_min_slice", &SdDebug::gemm_splitk_min_slice},
     {"gemm.no_table", &SdDebug::gemm_no_table},
+    {"gemm.persist_balance", &SdDebug::gemm_persist_balance},
     {"gemm.fwd_bump", &SdDebug::gemm_fwd_bump},
     {"model.fuse_student_swiglu", &SdDebug::model_fuse_student_swiglu},
     {"model.overlap_mask", &SdDebug::model_overlap_mask},

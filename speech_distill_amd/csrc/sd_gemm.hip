@@ -1571,7 +1571,12 @@ int launch(const void* A, const void* B, void* C, const void* R, float* slabs, i
         SD_STAMP_ARGS();                                                                                               \
         /* weight gradients (TA): the backward's persistent launches honour the CU budget of a multi-GPU run */       \
         const int cb = cu_budget(persist_grid, K);                                                                     \
-        const int pg = (TA && cb > 0 && cb < persist_grid) ? cb : persist_grid;                                        \
+        int pg = (TA && cb > 0 && cb < persist_grid) ? cb : persist_grid;                                              \
+        if (!TA && g_sd_debug.gemm_persist_balance) { /* (measurement) equal tiles per workgroup */                    \
+          const int nt = tiles_m * tiles_n, rounds = (nt + persist_grid - 1) / persist_grid;                           \
+          pg = (((nt + rounds - 1) / rounds) + 7) & ~7;                                                                \
+          if (pg > persist_grid) pg = persist_grid;                                                                    \
+        }                                                                                                              \
         hipLaunchKernelGGL((gemm_pstag_kernel<4, TA, TB, EPI>), dim3(pg), dim3(768), 0, st, (const bf16*)A,            \
                            (const bf16*)B, (bf16*)C, (const bf16*)R, M, N, K, lda, ldb, ldc, ldr, tiles_m, tiles_n,    \
                            gm, SD_STAMP_EA);                                                                           \
