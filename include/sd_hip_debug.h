@@ -13,6 +13,7 @@
  *                                       rows, bit1: 128 -> 256, bit2 / bit3: the same for the dX GEMMs, bit4: 64 -> 256,
  *                                       bit5 / bit6: the 128-row tile of bit0 / of the teacher with a 2-stage ring (two
  *                                       workgroups per CU); bits 2-6 were measured and lost
+ *   gemm.splitk_max            0        (measurement) most K slices the split-K plan may choose (0 = 8)
  *   gemm.persist_balance       0        (measurement) the persistent forward kernel starts as many workgroups as give each the
  *                                       same number of tiles (student gate|up: 192 x 2 tiles instead of 256 with 1 or 2)
  *   gemm.checked_staging       0        pointer staging with a zero page instead of buffer descriptors

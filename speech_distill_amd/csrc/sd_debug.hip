@@ -23,6 +23,7 @@ const Key kKeys[] = {
     {"gemm.tn_stag_min", &SdDebug::gemm_tn_stag_min},
     {"gemm.splitk_min_kt", &SdDebug::gemm_splitk_min_kt},
     {"gemm.splitk_min_slice", &SdDebug::gemm_splitk_min_slice},
+    {"gemm.splitk_max", &SdDebug::gemm_splitk_max},
     {"gemm.no_table", &SdDebug::gemm_no_table},
     {"gemm.persist_balance", &SdDebug::gemm_persist_balance},
     {"gemm.fwd_bump", &SdDebug::gemm_fwd_bump},

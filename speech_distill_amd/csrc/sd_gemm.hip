@@ -1756,7 +1756,8 @@ extern "C" int sd_gemm_splitk_plan(int M, int N, int K) {
   // fp32 slab; a slice keeps at least 24 K-steps).  48 tiles (lm_head dX on R = 1536 rows) -> 5 slices = 240
   // workgroups, not 8 = 384 = 1.5 rounds; 64 tiles -> 4.
   const int min_slice = g_sd_debug.gemm_splitk_min_slice < 1 ? 1 : g_sd_debug.gemm_splitk_min_slice;
-  const int cmax = kt / min_slice < 8 ? kt / min_slice : 8;
+  const int cap = g_sd_debug.gemm_splitk_max > 0 ? g_sd_debug.gemm_splitk_max : 8;  // (measurement knob)
+  const int cmax = kt / min_slice < cap ? kt / min_slice : cap;
   int s = 1;
   double best = (double)tiles / 256.0;
   for (int c = 2; c <= cmax; ++c) {
