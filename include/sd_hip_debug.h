@@ -31,9 +31,10 @@
  *   gemm.splitk_min_slice      24       least K/64 per slice (clamped to >= 1)
  *   gemm.no_table              0        ignore the measured shape -> variant table (csrc/sd_gemm_table.inc): heuristic only
  *   model.fuse_student_swiglu  0        SwiGLU in the gate|up GEMM epilogue also when gate|up is kept for the backward
- *   model.shared_layers        -1       decoder layers of a SD_FWD_CONCURRENT INFERENCE forward (the teacher) that run with the
- *                                       shared-GPU tiles; the rest run as if alone (-1 = all).  model.shared_layers_train: the
- *                                       same for a forward that saves activations (the student)
+ *   model.shared_layers / shared_layers_train   -1 / -1
+ *                                       decoder layers of a SD_FWD_CONCURRENT forward that run with the shared-GPU tiles, the
+ *                                       rest run as if alone (-1 = all): for an INFERENCE forward (the teacher) / for a forward
+ *                                       that saves activations (the student)
  *   model.overlap_mask         31       sd_qwen3_backward: bit0 lm_head dW, bit1 gain reduces, bit2 attention dQ on the side
  *                                       stream, bit3 grouped per-layer dW, bit4 one batched gain reduce per layer
  *   topk.nt                    0        threads per row of topk_kernel (256|512|1024; 0 = 512)
