@@ -33,7 +33,7 @@ import ctypes as C
 import json
 import math
 import os
-from dataclasses import asdict, dataclass, field, replace
+from dataclasses import asdict, dataclass, replace
 from typing import Sequence, Union
 
 import torch

@@ -11,6 +11,11 @@ memory -- no host synchronisation, ~8.5 GB of HBM traffic per step.
 ``grad_norm(max_grad_norm)`` so that HF's clipping (one ``clip_grad_norm_`` over ~310 tensors, 10 ms of host time)
 becomes one reduction plus a coefficient applied inside the update.  Stand-alone: ``FlatAdamW(student, clip=1.0)``.
 Weight decay applies to matrices only (norm gains are excluded, as HF's parameter grouping does).
+
+What it updates comes from ``model.optim_segments()``: for the fully trained student the one flat buffer; for a LoRA student
+(``lora.py``, train.py:180-202) the two saved modules in bf16 plus the adapter's fp32 masters (``sd_adamw_f32_shadow``: fp32
+moments, and the bf16 operands of the merge / projection kernels written in the same pass).  ``model.finalize_grads()`` runs
+first -- that is where a LoRA student projects the accumulated weight gradient onto its adapter.
 """
 import torch
 
