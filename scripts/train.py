@@ -44,6 +44,11 @@ def parse_args():
     # (vectorised collator), so the default here is the main process; workers are forked AFTER the GPU is initialised
     p.add_argument("--dataloader_num_workers", type=int, default=0)
     p.add_argument("--dataloader_prefetch_factor", type=int, default=2)  # train.py:536-541
+    p.add_argument("--blocking_h2d", action="store_true", help="(+) accelerate's default blocking host-to-device copies of "
+                   "the batch tensors (default here: non_blocking from the pinned buffers of the dataloader)")
+    p.add_argument("--logging_nan_inf_filter", type=lambda v: v.lower() not in ("0", "false", "no"), default=True,
+                   help="(+) HF TrainingArguments.logging_nan_inf_filter (HF default True = what the reference runs with): "
+                        "False drops HF's isnan/isinf host read of the loss after every micro-batch")
     # token strings (train.py:542-577): resolved through the tokenizer found in --student_model; without a tokenizer
     # directory the two ids the pre-processed path needs are given directly (--pad_token_id / --speech_bos_id)
     p.add_argument("--speech_bos", default="<|semantic_token_start|>")
@@ -173,7 +178,9 @@ def main():
         remove_unused_columns=False, label_names=["labels"], max_steps=cfg.max_steps, warmup_steps=cfg.warmup_steps,
         dataloader_num_workers=cfg.dataloader_num_workers,                                  # train.py:348-353
         dataloader_prefetch_factor=cfg.dataloader_prefetch_factor if cfg.dataloader_num_workers > 0 else None,
-        dataloader_pin_memory=True, seed=cfg.seed, **({"ddp_backend": cfg.ddp_backend} if cfg.ddp_backend else {}))     # train.py:331-354
+        dataloader_pin_memory=True, seed=cfg.seed, logging_nan_inf_filter=cfg.logging_nan_inf_filter,
+        **({} if cfg.blocking_h2d else {"accelerator_config": {"non_blocking": True}}),
+        **({"ddp_backend": cfg.ddp_backend} if cfg.ddp_backend else {}))     # train.py:331-354
     # Under torchrun the trainer wraps the student in ddp.HipDataParallel itself (DistillationTrainer._wrap_model):
     # bucketed RCCL all-reduce of the flat gradient under the backward, no_sync on accumulation micro-batches.
     trainer = DistillationTrainer(model=student, args=args, train_dataset=dataset, eval_dataset=eval_dataset,

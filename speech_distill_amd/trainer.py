@@ -38,6 +38,7 @@ class DistillationTrainer(Trainer):
         # stream beside the student forward (+4.5 % step throughput on MI355X); results are identical.
         self.overlap_teacher = True
         self._teacher_stream = None
+        self._rows_ahead = {}  # id(labels) -> (key, (rows, row_labels)) selected in get_batch_samples for this optimizer step
         # Training steps apply both lm_heads, the top-K and the loss only to the rows the loss reads (positions whose
         # NEXT label is not -100, distillation_loss.py:31-45) instead of computing all B*T rows and masking them
         # afterwards; loss and gradients are the same, the head is ~(masked fraction) cheaper.  Needs one host sync
@@ -131,6 +132,36 @@ class DistillationTrainer(Trainer):
             self.processing_class.save_pretrained(output_dir)
         torch.save(self.args, os.path.join(output_dir, "training_args.bin"))
 
+    @staticmethod
+    def _rows_key(lab, speech_mask, am, tam):
+        return (id(lab), lab.data_ptr(), tuple(lab.shape), None if speech_mask is None else speech_mask.data_ptr(),
+                None if am is None else am.data_ptr(), None if tam is None else tam.data_ptr())
+
+    def get_batch_samples(self, epoch_iterator, num_batches, device):
+        """HF fetches the micro-batches of one optimizer step here, together.  The loss-row selection of each needs one
+        host read (the row count); doing all of them now leaves the accumulation window itself free of host reads of
+        ours -- with ``logging_nan_inf_filter=False`` (HF's own per-micro-batch read) the host then enqueues the whole
+        window ahead of the GPU.  Same selection, same validation, same arguments as ``compute_loss`` would use."""
+        batch_samples, num_items = super().get_batch_samples(epoch_iterator, num_batches, device)
+        self._rows_ahead.clear()
+        core = ddp.unwrap(self.model)
+        if (self.compact_head and os.environ.get("SD_ROWS_AHEAD", "1") != "0" and isinstance(core, HipQwen3ForCausalLM)
+                and isinstance(self.distill_loss_fn, DistillationLoss)):
+            hip_teacher = isinstance(self.teacher_model, HipQwen3ForCausalLM)
+            for b in batch_samples:
+                lab = b.get("labels") if isinstance(b, dict) else None
+                if lab is None or not torch.is_tensor(lab) or not lab.is_cuda:
+                    continue
+                need_teacher = b.get("teacher_top_k_v") is None and self.teacher_model is not None
+                am = b.get("attention_mask")
+                tam = b.get("teacher_attention_mask") if hip_teacher and need_teacher else None
+                am = am if am is not None and tuple(am.shape) == tuple(lab.shape) else None
+                tam = tam if tam is not None and tuple(tam.shape) == tuple(lab.shape) else None
+                sm = b.get("speech_token_mask")
+                key = self._rows_key(lab, sm, am, tam)
+                self._rows_ahead[key[0]] = (key, ops.loss_rows(lab, sm, right_padded=(am, tam)))
+        return batch_samples, num_items
+
     def _load_best_model(self):
         """HF's loader looks for ``model.safetensors``; a LoRA student's checkpoints hold the adapter (``_save`` above)."""
         core = ddp.unwrap(self.model)
@@ -199,7 +230,12 @@ class DistillationTrainer(Trainer):
             am, tam = inputs.get("attention_mask"), (teacher_attention_mask if hip_teacher and need_teacher else None)
             am = am if am is not None and tuple(am.shape) == tuple(lab.shape) else None
             tam = tam if tam is not None and tuple(tam.shape) == tuple(lab.shape) else None
-            rows, row_labels = ops.loss_rows(lab, speech_mask, right_padded=(am, tam))
+            key = self._rows_key(lab, speech_mask, am, tam)
+            hit = self._rows_ahead.pop(key[0], None)
+            if hit is not None and hit[0] == key:   # selected with the accumulation window's other batches (get_batch_samples)
+                rows, row_labels = hit[1]
+            else:
+                rows, row_labels = ops.loss_rows(lab, speech_mask, right_padded=(am, tam))
             checked = {"padding_checked": True} if am is not None or inputs.get("attention_mask") is None else {}
             teacher_checked = {"padding_checked": True} if tam is not None or teacher_attention_mask is None else {}
             if rows.numel() == 0:  # N == 0: the full path returns the reference's zeros (distillation_loss.py:47-53)
