@@ -10,9 +10,8 @@ print("%-70s median %.0f  max %.0f  n=%d" % (sys.argv[1] or "(defaults)", sorted
 PY
 }
 if [ $# -gt 0 ]; then run "$@"; exit 0; fi
-run --blocking_h2d
 run
-run --logging_nan_inf_filter false
-run --blocking_h2d
+run --dataloader_num_workers 1
+run --dataloader_num_workers 2
 run
-run --logging_nan_inf_filter false
+run --dataloader_num_workers 1

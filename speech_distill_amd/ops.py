@@ -30,7 +30,7 @@ def _p(t):
 # RCCL add their own), so the side streams of the step are chosen by measurement: sd_streams_overlap runs a short
 # busy-wait on one stream and checks that the other is not held up behind it.
 _SIDE_STREAMS = {}  # (device index, role) -> torch.cuda.Stream
-_ROLES_ACTIVE_TOGETHER = {"teacher": (), "dw": ("comm",), "comm": ("dw",)}  # besides the main stream
+_ROLES_ACTIVE_TOGETHER = {"teacher": (), "dw": ("comm",), "comm": ("dw",), "h2d": ("teacher",)}  # besides the main stream
 
 
 def streams_overlap(a, b, spin_us=200.0):
@@ -42,7 +42,8 @@ def streams_overlap(a, b, spin_us=200.0):
 
 def concurrent_stream(device, role):
     """The process-wide side stream of ``role`` on ``device``: "teacher" (frozen teacher beside the student forward),
-    "dw" (weight-gradient GEMMs beside the dX chain), "comm" (gradient all-reduce beside backward).  Picked once, by
+    "dw" (weight-gradient GEMMs beside the dX chain), "comm" (gradient all-reduce beside backward), "h2d" (the next
+    accumulation window's batches, copied in while the optimizer step is still running: DistillationTrainer.get_batch_samples).  Picked once, by
     experiment, so that it overlaps the current (main) stream and the roles that are busy at the same time; the
     environment variable SD_STREAM_PICK=0 takes the first stream torch hands out instead."""
     device = torch.device(device)

@@ -38,7 +38,8 @@ class DistillationTrainer(Trainer):
         # stream beside the student forward (+4.5 % step throughput on MI355X); results are identical.
         self.overlap_teacher = True
         self._teacher_stream = None
-        self._rows_ahead = {}  # id(labels) -> (key, (rows, row_labels)) selected in get_batch_samples for this optimizer step
+        self._rows_ahead = {}  # id(labels) -> (key, (rows, row_labels), event) selected in get_batch_samples for this optimizer step
+        self._copy_stream = None
         # Training steps apply both lm_heads, the top-K and the loss only to the rows the loss reads (positions whose
         # NEXT label is not -100, distillation_loss.py:31-45) instead of computing all B*T rows and masking them
         # afterwards; loss and gradients are the same, the head is ~(masked fraction) cheaper.  Needs one host sync
@@ -138,16 +139,32 @@ class DistillationTrainer(Trainer):
                 None if am is None else am.data_ptr(), None if tam is None else tam.data_ptr())
 
     def get_batch_samples(self, epoch_iterator, num_batches, device):
-        """HF fetches the micro-batches of one optimizer step here, together.  The loss-row selection of each needs one
-        host read (the row count); doing all of them now leaves the accumulation window itself free of host reads of
-        ours -- with ``logging_nan_inf_filter=False`` (HF's own per-micro-batch read) the host then enqueues the whole
-        window ahead of the GPU.  Same selection, same validation, same arguments as ``compute_loss`` would use."""
-        batch_samples, num_items = super().get_batch_samples(epoch_iterator, num_batches, device)
-        self._rows_ahead.clear()
+        """HF fetches the micro-batches of one optimizer step here, together, right after it has enqueued the previous
+        optimizer step.  Two things are done with that (``SD_ROWS_AHEAD=0`` turns both off):
+
+        * the loss-row selection of every micro-batch (one host read each: the row count) happens now, so the
+          accumulation window itself has no host reads of ours -- with ``logging_nan_inf_filter=False`` (HF's own
+          per-micro-batch read) the host enqueues the whole window ahead of the GPU;
+        * the fetch -- accelerate's host-to-device copies, HF's token count, the row selection -- runs on a stream of its
+          own ("h2d"): none of it depends on the optimizer kernels still queued on the main stream, and the frozen
+          teacher's pass in ``compute_loss`` then waits for THAT stream's event only, i.e. the teacher's forward of the
+          window's first micro-batch runs beside the AdamW update (HBM-bound) instead of after it.
+
+        Same selection, validation and arguments as ``compute_loss`` would use on its own."""
         core = ddp.unwrap(self.model)
-        if (self.compact_head and os.environ.get("SD_ROWS_AHEAD", "1") != "0" and isinstance(core, HipQwen3ForCausalLM)
-                and isinstance(self.distill_loss_fn, DistillationLoss)):
-            hip_teacher = isinstance(self.teacher_model, HipQwen3ForCausalLM)
+        ahead = (self.compact_head and os.environ.get("SD_ROWS_AHEAD", "1") != "0" and isinstance(core, HipQwen3ForCausalLM)
+                 and core.flat.is_cuda and isinstance(self.distill_loss_fn, DistillationLoss))
+        self._rows_ahead.clear()
+        if not ahead:
+            return super().get_batch_samples(epoch_iterator, num_batches, device)
+        main = torch.cuda.current_stream(core.flat.device)
+        if self._copy_stream is None:
+            self._copy_stream = ops.concurrent_stream(core.flat.device, "h2d")
+        cs = self._copy_stream
+        hip_teacher = isinstance(self.teacher_model, HipQwen3ForCausalLM)
+        with torch.cuda.stream(cs):
+            batch_samples, num_items = super().get_batch_samples(epoch_iterator, num_batches, device)
+            selected = []
             for b in batch_samples:
                 lab = b.get("labels") if isinstance(b, dict) else None
                 if lab is None or not torch.is_tensor(lab) or not lab.is_cuda:
@@ -158,8 +175,19 @@ class DistillationTrainer(Trainer):
                 am = am if am is not None and tuple(am.shape) == tuple(lab.shape) else None
                 tam = tam if tam is not None and tuple(tam.shape) == tuple(lab.shape) else None
                 sm = b.get("speech_token_mask")
-                key = self._rows_key(lab, sm, am, tam)
-                self._rows_ahead[key[0]] = (key, ops.loss_rows(lab, sm, right_padded=(am, tam)))
+                selected.append((self._rows_key(lab, sm, am, tam), ops.loss_rows(lab, sm, right_padded=(am, tam))))
+            ready = torch.cuda.Event()
+            ready.record(cs)
+        main.wait_event(ready)
+        # the tensors were allocated on the copy stream and are used on the main and the teacher's stream
+        users = [main] + ([self._teacher_stream] if self._teacher_stream is not None else [])
+        held = [t for b in batch_samples if isinstance(b, dict) for t in b.values() if torch.is_tensor(t) and t.is_cuda]
+        held += [t for _, rr in selected for t in rr] + ([num_items] if torch.is_tensor(num_items) and num_items.is_cuda else [])
+        for t in held:
+            for st in users:
+                t.record_stream(st)
+        for key, rr in selected:
+            self._rows_ahead[key[0]] = (key, rr, ready)
         return batch_samples, num_items
 
     def _load_best_model(self):
@@ -218,6 +246,7 @@ class DistillationTrainer(Trainer):
         hip_teacher = isinstance(self.teacher_model, HipQwen3ForCausalLM)
         vocab = getattr(getattr(core, "dims", None), "vocab_size", None)  # only our own model type is overlapped
         side = None
+        fetched = None
         ids = inputs.get("input_ids")
         rows = row_labels = None
         lab = inputs.get("labels")
@@ -234,6 +263,7 @@ class DistillationTrainer(Trainer):
             hit = self._rows_ahead.pop(key[0], None)
             if hit is not None and hit[0] == key:   # selected with the accumulation window's other batches (get_batch_samples)
                 rows, row_labels = hit[1]
+                fetched = hit[2]                    # event: this batch (and its rows) are on the device
             else:
                 rows, row_labels = ops.loss_rows(lab, speech_mask, right_padded=(am, tam))
             checked = {"padding_checked": True} if am is not None or inputs.get("attention_mask") is None else {}
@@ -248,7 +278,13 @@ class DistillationTrainer(Trainer):
             if self._teacher_stream is None:
                 self._teacher_stream = ops.concurrent_stream(ids.device, "teacher")
             side = self._teacher_stream
-            side.wait_stream(torch.cuda.current_stream())
+            if fetched is not None:   # the teacher needs the batch, not whatever else the main stream still has queued
+                side.wait_event(fetched)
+                for t in (ids, teacher_input_ids, teacher_attention_mask, inputs.get("attention_mask"), rows):
+                    if torch.is_tensor(t) and t.is_cuda:
+                        t.record_stream(side)
+            else:
+                side.wait_stream(torch.cuda.current_stream())
             # two passes share the GPU from here to the loss: both are told (SD_FWD_CONCURRENT, include/sd_hip.h)
             teacher_kw = dict(teacher_kw, concurrent=True)
             if hip_student:
@@ -268,6 +304,9 @@ class DistillationTrainer(Trainer):
         teacher_logits_local = None
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)
+            for t in (teacher_logits, teacher_top_k_v, teacher_top_k_i):   # allocated on the teacher's stream, read on this one
+                if torch.is_tensor(t) and t.is_cuda:
+                    t.record_stream(torch.cuda.current_stream())
             teacher_logits_local = teacher_logits
         elif need_teacher:  # reference order: student first, then teacher (train.py:60-94)
             teacher_logits_local, teacher_top_k_v, teacher_top_k_i = self._teacher_pass(
