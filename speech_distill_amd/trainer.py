@@ -40,6 +40,12 @@ class DistillationTrainer(Trainer):
         self._teacher_stream = None
         self._rows_ahead = {}  # id(labels) -> (key, (rows, row_labels), event) selected in get_batch_samples for this optimizer step
         self._copy_stream = None
+        # The teacher's pass of micro-batch i+1 of an accumulation window is enqueued at the END of training_step(i): HF's
+        # per-micro-batch host read (logging_nan_inf_filter, on by default) drains the main stream after every backward,
+        # and the GPU then has the next teacher pass to run while the host walks back to compute_loss (+1.6-2.1 % loop
+        # throughput; with HF's read off the host is ahead anyway and it measured -0.5 %, so "auto" follows that flag).
+        # SD_TEACHER_AHEAD=0 / 1 forces it.
+        self._window, self._ahead_results = [], {}
         # Training steps apply both lm_heads, the top-K and the loss only to the rows the loss reads (positions whose
         # NEXT label is not -100, distillation_loss.py:31-45) instead of computing all B*T rows and masking them
         # afterwards; loss and gradients are the same, the head is ~(masked fraction) cheaper.  Needs one host sync
@@ -188,7 +194,47 @@ class DistillationTrainer(Trainer):
                 t.record_stream(st)
         for key, rr in selected:
             self._rows_ahead[key[0]] = (key, rr, ready)
+        self._window, self._ahead_results = list(batch_samples), {}
         return batch_samples, num_items
+
+    _TEACHER_SIDE_KEYS = ("teacher_input_ids", "teacher_attention_mask", "speech_token_mask", "teacher_top_k_v", "teacher_top_k_i")
+
+    def training_step(self, model, inputs, *args, **kwargs):
+        lab = inputs.get("labels") if isinstance(inputs, dict) else None
+        loss = super().training_step(model, inputs, *args, **kwargs)
+        mode = os.environ.get("SD_TEACHER_AHEAD", "auto")
+        if lab is not None and self._window and (mode == "1" or (mode == "auto" and self.args.logging_nan_inf_filter)):
+            self._launch_teacher_ahead(id(lab))
+        return loss
+
+    def _launch_teacher_ahead(self, cur_id):
+        """Enqueue the frozen teacher's pass for the micro-batch that follows ``cur_id`` in this accumulation window."""
+        idx = next((i for i, b in enumerate(self._window) if isinstance(b, dict) and id(b.get("labels")) == cur_id), None)
+        if idx is None or idx + 1 >= len(self._window):
+            return
+        nxt = self._window[idx + 1]
+        lab = nxt.get("labels")
+        entry = self._rows_ahead.get(id(lab))
+        core = ddp.unwrap(self.model)
+        ids, tids = nxt.get("input_ids"), nxt.get("teacher_input_ids")
+        if (entry is None or entry[1][0].numel() == 0 or not self.overlap_teacher or nxt.get("teacher_top_k_v") is not None
+                or not isinstance(self.teacher_model, HipQwen3ForCausalLM) or not isinstance(core, HipQwen3ForCausalLM)
+                or ids is None or (tids is not None and tuple(tids.shape) != tuple(ids.shape))):
+            return
+        _, (rows, _), fetched = entry
+        tam = nxt.get("teacher_attention_mask")
+        aligned = tam is not None and tuple(tam.shape) == tuple(lab.shape)
+        kw = dict({"padding_checked": True} if aligned or tam is None else {}, concurrent=True)
+        if self._teacher_stream is None:
+            self._teacher_stream = ops.concurrent_stream(ids.device, "teacher")
+        side = self._teacher_stream
+        side.wait_event(fetched)
+        for t in (ids, tids, tam, nxt.get("attention_mask"), rows):
+            if torch.is_tensor(t) and t.is_cuda:
+                t.record_stream(side)
+        base = {k: v for k, v in nxt.items() if k not in self._TEACHER_SIDE_KEYS}
+        with torch.cuda.stream(side):
+            self._ahead_results[id(lab)] = self._teacher_pass(base, tids, tam, core.dims.vocab_size, rows, kw)
 
     def _load_best_model(self):
         """HF's loader looks for ``model.safetensors``; a LoRA student's checkpoints hold the adapter (``_save`` above)."""
@@ -273,7 +319,13 @@ class DistillationTrainer(Trainer):
         else:
             teacher_checked = {}
         teacher_kw = teacher_checked if hip_teacher else {}
-        if (need_teacher and self.overlap_teacher and vocab is not None and ids is not None and ids.is_cuda
+        ahead = self._ahead_results.pop(id(lab), None) if fetched is not None and rows is not None else None
+        if ahead is not None:   # SD_TEACHER_AHEAD: this batch's teacher pass was enqueued at the end of the previous micro-step
+            side = self._teacher_stream
+            teacher_logits, teacher_top_k_v, teacher_top_k_i = ahead
+            if hip_student:
+                checked = dict(checked, concurrent=True)
+        elif (need_teacher and self.overlap_teacher and vocab is not None and ids is not None and ids.is_cuda
                 and hip_teacher):
             if self._teacher_stream is None:
                 self._teacher_stream = ops.concurrent_stream(ids.device, "teacher")
