@@ -14,6 +14,8 @@
  *                                       bit5 / bit6: the 128-row tile of bit0 / of the teacher with a 2-stage ring (two
  *                                       workgroups per CU); bits 2-6 were measured and lost
  *   gemm.splitk_max            0        (measurement) most K slices the split-K plan may choose (0 = 8)
+ *   gemm.fwd_cu_budget         0        (measurement) workgroups of the persistent 256x128 FORWARD launches of a
+ *                                       SD_FWD_CONCURRENT pass (teacher / student gate|up); 0 = one per CU
  *   gemm.persist_balance       0        (measurement) the persistent forward kernel starts as many workgroups as give each the
  *                                       same number of tiles (student gate|up: 192 x 2 tiles instead of 256 with 1 or 2)
  *   gemm.checked_staging       0        pointer staging with a zero page instead of buffer descriptors

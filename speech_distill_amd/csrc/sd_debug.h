@@ -14,6 +14,7 @@ struct SdDebug {
   int gemm_tn_stag_min = 1024;
   int gemm_splitk_min_kt = 96, gemm_splitk_min_slice = 24;
   int gemm_splitk_max = 0;  // (measurement) most K slices the split-K plan may choose (0 = 8)
+  int gemm_fwd_cu_budget = 0;    // (measurement) workgroups of the persistent FORWARD launches of a SD_FWD_CONCURRENT pass (0 = one per CU)
   int gemm_persist_balance = 0;  // (measurement) persistent forward launches: as many workgroups as give every one the same number of tiles
   int gemm_no_table = 0;  // ignore the measured shape -> variant table (sd_gemm_table.inc)
   // tiles of a pass that shares the GPU with another stream (SD_FWD_CONCURRENT): 0 = follow the caller's flag (then bits

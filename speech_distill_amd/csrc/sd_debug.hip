@@ -26,6 +26,7 @@ const Key kKeys[] = {
     {"gemm.splitk_max", &SdDebug::gemm_splitk_max},
     {"gemm.no_table", &SdDebug::gemm_no_table},
     {"gemm.persist_balance", &SdDebug::gemm_persist_balance},
+    {"gemm.fwd_cu_budget", &SdDebug::gemm_fwd_cu_budget},
     {"gemm.fwd_bump", &SdDebug::gemm_fwd_bump},
     {"model.fuse_student_swiglu", &SdDebug::model_fuse_student_swiglu},
     {"model.overlap_mask", &SdDebug::model_overlap_mask},

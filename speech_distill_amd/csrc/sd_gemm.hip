@@ -1572,6 +1572,8 @@ int launch(const void* A, const void* B, void* C, const void* R, float* slabs, i
         /* weight gradients (TA): the backward's persistent launches honour the CU budget of a multi-GPU run */       \
         const int cb = cu_budget(persist_grid, K);                                                                     \
         int pg = (TA && cb > 0 && cb < persist_grid) ? cb : persist_grid;                                              \
+        if (!TA && g_sd_debug.gemm_fwd_cu_budget > 0 && t_sd_shared_gpu && g_sd_debug.gemm_fwd_cu_budget < pg)         \
+          pg = g_sd_debug.gemm_fwd_cu_budget & ~7; /* (measurement) forward persistent launches beside another stream */ \
         if (!TA && g_sd_debug.gemm_persist_balance) { /* (measurement) equal tiles per workgroup */                    \
           const int nt = tiles_m * tiles_n, rounds = (nt + persist_grid - 1) / persist_grid;                           \
           pg = (((nt + rounds - 1) / rounds) + 7) & ~7;                                                                \
