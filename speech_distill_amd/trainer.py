@@ -45,7 +45,7 @@ class DistillationTrainer(Trainer):
         # and the GPU then has the next teacher pass to run while the host walks back to compute_loss (+1.6-2.1 % loop
         # throughput; with HF's read off the host is ahead anyway and it measured -0.5 %, so "auto" follows that flag).
         # SD_TEACHER_AHEAD=0 / 1 forces it.
-        self._window, self._ahead_results = [], {}
+        self._window, self._window_next, self._ahead_results, self._prefetched = [], [], {}, None
         # Training steps apply both lm_heads, the top-K and the loss only to the rows the loss reads (positions whose
         # NEXT label is not -100, distillation_loss.py:31-45) instead of computing all B*T rows and masking them
         # afterwards; loss and gradients are the same, the head is ~(masked fraction) cheaper.  Needs one host sync
@@ -160,9 +160,38 @@ class DistillationTrainer(Trainer):
         core = ddp.unwrap(self.model)
         ahead = (self.compact_head and os.environ.get("SD_ROWS_AHEAD", "1") != "0" and isinstance(core, HipQwen3ForCausalLM)
                  and core.flat.is_cuda and isinstance(self.distill_loss_fn, DistillationLoss))
-        self._rows_ahead.clear()
         if not ahead:
+            self._rows_ahead.clear()
+            self._window, self._window_next, self._ahead_results, self._prefetched = [], [], {}, None
             return super().get_batch_samples(epoch_iterator, num_batches, device)
+        # window k comes from the previous call's lookahead when there is one (same iterator object = same epoch)
+        pre, self._prefetched = self._prefetched, None
+        if pre is not None and pre[0] is epoch_iterator:
+            batch_samples, num_items, selected, ready = pre[1]
+        else:
+            batch_samples, num_items, selected, ready = self._fetch_window(core, epoch_iterator, num_batches, device)
+        main = torch.cuda.current_stream(core.flat.device)
+        main.wait_event(ready)
+        live = {id(b.get("labels")) for b in batch_samples if isinstance(b, dict)}
+        self._rows_ahead = {k: v for k, v in self._rows_ahead.items() if k in live}
+        self._ahead_results = {k: v for k, v in self._ahead_results.items() if k in live}
+        for key, rr in selected:
+            self._rows_ahead[key[0]] = (key, rr, ready)
+        self._window, self._window_next = list(batch_samples), []
+        # ... and window k+1 is fetched NOW (lock-step host only: HF's per-micro-batch read on), so that the last
+        # training_step of window k can enqueue the teacher's pass for its first micro-batch beside the optimizer step
+        mode = os.environ.get("SD_WINDOW_AHEAD", "auto")
+        if batch_samples and (mode == "1" or (mode == "auto" and self.args.logging_nan_inf_filter)):
+            nxt = self._fetch_window(core, epoch_iterator, num_batches, device)
+            self._prefetched = (epoch_iterator, nxt)
+            self._window_next = list(nxt[0])
+            for key, rr in nxt[2]:
+                self._rows_ahead[key[0]] = (key, rr, nxt[3])
+        return batch_samples, num_items
+
+    def _fetch_window(self, core, epoch_iterator, num_batches, device):
+        """HF's fetch of one accumulation window + the loss-row selection of its micro-batches, on the copy stream.
+        Returns (batch_samples, num_items_in_batch, [(key, (rows, row_labels))], event)."""
         main = torch.cuda.current_stream(core.flat.device)
         if self._copy_stream is None:
             self._copy_stream = ops.concurrent_stream(core.flat.device, "h2d")
@@ -184,7 +213,6 @@ class DistillationTrainer(Trainer):
                 selected.append((self._rows_key(lab, sm, am, tam), ops.loss_rows(lab, sm, right_padded=(am, tam))))
             ready = torch.cuda.Event()
             ready.record(cs)
-        main.wait_event(ready)
         # the tensors were allocated on the copy stream and are used on the main and the teacher's stream
         users = [main] + ([self._teacher_stream] if self._teacher_stream is not None else [])
         held = [t for b in batch_samples if isinstance(b, dict) for t in b.values() if torch.is_tensor(t) and t.is_cuda]
@@ -192,10 +220,7 @@ class DistillationTrainer(Trainer):
         for t in held:
             for st in users:
                 t.record_stream(st)
-        for key, rr in selected:
-            self._rows_ahead[key[0]] = (key, rr, ready)
-        self._window, self._ahead_results = list(batch_samples), {}
-        return batch_samples, num_items
+        return batch_samples, num_items, selected, ready
 
     _TEACHER_SIDE_KEYS = ("teacher_input_ids", "teacher_attention_mask", "speech_token_mask", "teacher_top_k_v", "teacher_top_k_i")
 
@@ -209,10 +234,11 @@ class DistillationTrainer(Trainer):
 
     def _launch_teacher_ahead(self, cur_id):
         """Enqueue the frozen teacher's pass for the micro-batch that follows ``cur_id`` in this accumulation window."""
-        idx = next((i for i, b in enumerate(self._window) if isinstance(b, dict) and id(b.get("labels")) == cur_id), None)
-        if idx is None or idx + 1 >= len(self._window):
+        seq = self._window + self._window_next   # (the next window's first micro-batch follows this window's last)
+        idx = next((i for i, b in enumerate(seq) if isinstance(b, dict) and id(b.get("labels")) == cur_id), None)
+        if idx is None or idx + 1 >= len(seq):
             return
-        nxt = self._window[idx + 1]
+        nxt = seq[idx + 1]
         lab = nxt.get("labels")
         entry = self._rows_ahead.get(id(lab))
         core = ddp.unwrap(self.model)
