@@ -368,3 +368,54 @@ def test_teacher_batch_of_another_length_is_refused_on_the_gpu_path(sda):
     a = tr.compute_loss(student, dict(base, labels=to_dev(labels)))
     b = tr.compute_loss(student, dict(base, labels=to_dev(labels.to(torch.int32))))
     assert float(a) == float(b) and float(a) > 0
+
+
+def test_window_lookahead_serves_the_same_batches_in_the_same_order(sda, monkeypatch):
+    """DistillationTrainer.get_batch_samples fetches one accumulation window ahead and training_step enqueues the next
+    micro-batch's teacher pass early (both only re-order host work).  Over two epochs whose last window is a remainder
+    (13 samples, batch 2, accumulation 2: 7 micro-batches = 4 optimizer steps per epoch, the last with one micro-batch
+    of one sample), the loop must see the same micro-batches in the same order, log the same losses and end at the
+    same parameters as with the plain HF order (SD_ROWS_AHEAD=0)."""
+    import tempfile
+    from transformers import TrainingArguments
+    from speech_distill_amd.collator import ProcessedDataCollator
+    from speech_distill_amd.trainer import DistillationTrainer
+    z, st, te, sw, tw, feats, pad, bos = _c1(sda)
+    rows = (feats * 2)[:13]
+
+    class DS(torch.utils.data.Dataset):
+        def __len__(self):
+            return len(rows)
+
+        def __getitem__(self, i):
+            return dict(rows[i])
+
+    def run(ahead):
+        monkeypatch.setenv("SD_ROWS_AHEAD", "1" if ahead else "0")
+        student, teacher = _build(sda, st, sw), _build(sda, te, tw)
+        teacher.eval().requires_grad_(False)
+        args = TrainingArguments(
+            output_dir=tempfile.mkdtemp(), per_device_train_batch_size=2, gradient_accumulation_steps=2, num_train_epochs=2,
+            learning_rate=1e-3, logging_steps=1, save_strategy="no", eval_strategy="no", report_to=[],
+            remove_unused_columns=False, label_names=["labels"], seed=7, data_seed=7, lr_scheduler_type="constant",
+            warmup_steps=0, max_grad_norm=1.0, dataloader_num_workers=0, bf16=True)
+        tr = DistillationTrainer(model=student, args=args, train_dataset=DS(), teacher_model=teacher, temperature=2.0,
+                                 alpha=0.5, top_k=16, data_collator=ProcessedDataCollator(_Tok(pad, bos), pad_token_id=pad))
+        seen, early = [], []
+        inner = tr.compute_loss
+
+        def spy(model, inputs, *a, **k):
+            seen.append(inputs["input_ids"].cpu().clone())
+            early.append(id(inputs["labels"]) in tr._ahead_results)
+            return inner(model, inputs, *a, **k)
+        tr.compute_loss = spy
+        tr.train()
+        return seen, early, [h["loss"] for h in tr.state.log_history if "loss" in h], student.flat.clone()
+    seen_a, early_a, loss_a, flat_a = run(True)
+    seen_b, early_b, loss_b, flat_b = run(False)
+    assert len(seen_a) == len(seen_b) == 14 and len(loss_a) == 8
+    for a, b in zip(seen_a, seen_b):
+        assert a.shape == b.shape and torch.equal(a, b)
+    assert loss_a == loss_b and torch.equal(flat_a, flat_b)
+    # with the lookahead every micro-batch but the first of an epoch found its teacher pass already enqueued
+    assert not any(early_b) and early_a == [False] + [True] * 6 + [False] + [True] * 6, early_a
